@@ -1,0 +1,65 @@
+"""ctypes binding of libisg.so (the C ABI declared in include/isg.h).
+
+The library is built in-tree by ``imagesegmentation_amd.build``; there is no CPU fallback: if the
+shared object is missing, or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libisg.so")
+
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/isg.h one to one
+SIGNATURES = {
+    "isg_version": (_int, []),
+    "isg_last_error": (ctypes.c_char_p, []),
+    "isg_raster_iou": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "isg_shape_mask": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "isg_history_frames": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _int, _vp]),
+}
+
+_lib = None
+
+
+class IsgError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises ImportError with build instructions when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libisg.so not found at %s - build it first: python -m imagesegmentation_amd.build" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().isg_last_error().decode("utf-8", "replace")
+        raise IsgError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("libisg needs contiguous tensors")
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

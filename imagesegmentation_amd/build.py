@@ -1,0 +1,53 @@
+"""In-tree build of libisg.so for gfx950:  python -m imagesegmentation_amd.build [--force]"""
+import glob
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OUT = os.path.join(_HERE, "libisg.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "isg.h")]
+    newest = max(os.path.getmtime(p) for p in deps)
+    return os.path.getmtime(OUT) < newest
+
+
+def build(force=False, verbose=True):
+    """Compiles every csrc/*.hip into one shared object with hipcc (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return OUT
+    objs = []
+    procs = []
+    objdir = os.path.join(_HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on %s" % src)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built", OUT)

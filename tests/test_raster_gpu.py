@@ -1,0 +1,193 @@
+"""HIP rasteriser / IoU / environments against the oracle and the reference-made fixtures."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import raster as oracle_raster
+from conftest import unpack_masks
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _oracle_batch(vp, nvp, vt, nvt, size, masks=True):
+    lib = oracle.load_c()
+    n, vmax = vp.shape[0], vp.shape[1]
+    inter, union = np.zeros([n], np.int32), np.zeros([n], np.int32)
+    mp = np.zeros([n, size, size], np.uint8) if masks else None
+    mt = np.zeros([n, size, size], np.uint8) if masks else None
+    i32p, u8p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8)
+    cast = lambda a, t: a.ctypes.data_as(t) if a is not None else None
+    lib.isg_oracle_raster_iou(cast(vp, i32p), cast(nvp, i32p), cast(vt, i32p), cast(nvt, i32p), n, vmax, size,
+                              cast(inter, i32p), cast(union, i32p), cast(mp, u8p), cast(mt, u8p), 8)
+    return inter, union, mp, mt
+
+
+@pytest.mark.parametrize("size", (8, 28, 32, 224))
+def test_masks_and_counts_match_reference_fixtures(raster_golden, size):
+    from imagesegmentation_amd import util
+    dev = _dev()
+    verts = np.ascontiguousarray(raster_golden["verts_%d" % size])
+    nverts = np.ascontiguousarray(raster_golden["nverts_%d" % size])
+    vt, nt = np.ascontiguousarray(np.roll(verts, -1, axis=0)), np.ascontiguousarray(np.roll(nverts, -1, axis=0))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    inter, union, mp, mt = util.raster_iou(t(verts), t(nverts), t(vt), t(nt), size, want_masks=True)
+    ref = unpack_masks(raster_golden["masks_%d" % size], size)
+    assert np.array_equal(mp.cpu().numpy(), ref)
+    assert np.array_equal(mt.cpu().numpy(), np.roll(ref, -1, axis=0))
+    assert np.array_equal(inter.cpu().numpy(), raster_golden["inter_%d" % size])
+    assert np.array_equal(union.cpu().numpy(), raster_golden["union_%d" % size])
+    iou = (inter.double() / union.double()).cpu().numpy()
+    assert np.array_equal(iou, raster_golden["iou_%d" % size])
+    # masks-off mode gives the same counts; single-polygon entry point gives the same masks + areas
+    i2, u2 = util.raster_iou(t(verts), t(nverts), t(vt), t(nt), size)
+    assert torch.equal(i2, inter) and torch.equal(u2, union)
+    m1, area = util.shape_masks(t(verts), t(nverts), size, want_area=True)
+    assert np.array_equal(m1.cpu().numpy(), ref)
+    assert np.array_equal(area.cpu().numpy(), raster_golden["area_%d" % size])
+
+
+@pytest.mark.parametrize("size,n,vmax", [(28, 5000, 16), (32, 3001, 13), (224, 600, 16), (100, 257, 16), (30, 300, 8),
+                                         (37, 123, 16), (512, 9, 16), (1, 5, 4), (64, 65, 64)])
+def test_random_polygons_match_c_oracle(size, n, vmax):
+    from imagesegmentation_amd import util
+    dev = _dev()
+    rs = np.random.RandomState(size * 1000 + n)
+    nvp = rs.randint(0, vmax + 1, [n]).astype(np.int32)   # includes empty and full vertex lists
+    nvt = rs.randint(1, min(vmax, 9) + 1, [n]).astype(np.int32)
+    vp = rs.randint(-3, size + 3, [n, vmax, 2]).astype(np.int32)  # some vertices just outside: clipped
+    vt = rs.randint(0, size, [n, vmax, 2]).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    inter, union, mp, mt = util.raster_iou(t(vp), t(nvp), t(vt), t(nvt), size, want_masks=True)
+    oi, ou, omp, omt = _oracle_batch(vp, nvp, vt, nvt, size)
+    assert np.array_equal(mp.cpu().numpy(), omp)
+    assert np.array_equal(mt.cpu().numpy(), omt)
+    assert np.array_equal(inter.cpu().numpy(), oi)
+    assert np.array_equal(union.cpu().numpy(), ou)
+
+
+def test_full_size_properties_16k_rollouts_at_224():
+    """Size-independent properties at the benchmark's size: IoU(p, p) == 1, symmetry, and
+    inter + union == area_p + area_t."""
+    from imagesegmentation_amd import util
+    dev = _dev()
+    n, size, vmax = 16384, 224, 16
+    rs = np.random.RandomState(5)
+    nv = rs.randint(3, 14, [n]).astype(np.int32)
+    va = rs.randint(0, size, [n, vmax, 2]).astype(np.int32)
+    vb = rs.randint(0, size, [n, vmax, 2]).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    A, NA, B = t(va), t(nv), t(vb)
+    i_ab, u_ab = util.raster_iou(A, NA, B, NA, size)
+    i_ba, u_ba = util.raster_iou(B, NA, A, NA, size)
+    assert torch.equal(i_ab, i_ba) and torch.equal(u_ab, u_ba)
+    i_aa, u_aa = util.raster_iou(A, NA, A, NA, size)
+    assert torch.equal(i_aa, u_aa)
+    _, area_a = util.shape_masks(A, NA, size, want_area=True)
+    _, area_b = util.shape_masks(B, NA, size, want_area=True)
+    assert torch.equal(i_aa, area_a)
+    assert torch.equal(i_ab + u_ab, area_a + area_b)
+    # spot-check 64 of them against the oracle
+    sel = rs.choice(n, 64, replace=False)
+    oi, ou, _, _ = _oracle_batch(np.ascontiguousarray(va[sel]), np.ascontiguousarray(nv[sel]),
+                                 np.ascontiguousarray(vb[sel]), np.ascontiguousarray(nv[sel]), size, masks=False)
+    assert np.array_equal(i_ab.cpu().numpy()[sel], oi) and np.array_equal(u_ab.cpu().numpy()[sel], ou)
+
+
+def test_scalar_api_matches_reference_behaviour(raster_golden, env_golden):
+    from imagesegmentation_amd import util
+    _dev()
+    size = 28
+    verts, nverts = raster_golden["verts_28"], raster_golden["nverts_28"]
+    ref = unpack_masks(raster_golden["masks_28"], size)
+    for i in (0, 1, 2, 3, 7, 299, 300, 449):
+        m = util.create_shape_mask(verts[i, :nverts[i]], size)
+        assert m.dtype == np.float64 and m.shape == (size, size)
+        assert np.array_equal(m.astype(np.uint8), ref[i])
+        j = (i + 1) % len(verts)
+        assert util.calculate_iou(verts[i, :nverts[i]], verts[j, :nverts[j]], size) == raster_golden["iou_28"][i]
+    for p in ([[0, 0], [8, 0], [8, 5]], [[3, 3], [3, 9], [5, 5]]):
+        with pytest.raises(IndexError):
+            util.create_shape_mask(np.array(p), 8)
+
+
+class ReplayDataset:
+    def __init__(self, size, hist, image, verts):
+        self._prediction_size, self._history_length = size, hist
+        self._image, self._verts = image, verts
+
+    def raw_sample(self, batch_size):
+        vs = np.empty([batch_size], dtype=object)
+        for i in range(batch_size):
+            vs[i] = self._verts
+        return np.array([self._image] * batch_size), vs
+
+
+def _summary(state):
+    return {"shape": list(state.shape), "hist_nonzero": np.argwhere(state[:, :, 3:] != 0).tolist(),
+            "image_sum": float(state[:, :, :3].sum())}
+
+
+def test_scalar_envs_replay_reference_traces(env_golden):
+    from imagesegmentation_amd.polyrl import polygon_env, polygon_env_end_token
+    _dev()
+    for tr in env_golden["env_traces"]:
+        size, hist = tr["size"], tr["hist"]
+        verts = np.array(tr["vertices"])
+        image = np.stack([oracle_raster.create_shape_mask(verts, size)] * 3, axis=2)
+        mod = polygon_env if tr["variant"] == "close" else polygon_env_end_token
+        env = mod.PolygonEnv(ReplayDataset(size, hist, image, verts))
+        st = env.reset()
+        assert st.dtype == np.float64 and _summary(st) == tr["reset"]
+        for s in tr["steps"]:
+            st, reward, done = env.step(s["action"])
+            assert reward == s["reward"] and done == s["done"]
+            assert _summary(st) == s["state"]
+            assert np.array(env.predicted_vertices).tolist() == s["predicted_vertices"]
+        if tr["steps"] and tr["steps"][-1]["done"]:
+            with pytest.raises(NotImplementedError, match="Didn't reset a finished environment!"):
+                env.step(tr["steps"][-1]["action"])
+            assert tr["step_after_done"] == "Didn't reset a finished environment!"
+
+
+def test_batched_env_replays_reference_traces(env_golden):
+    """All traces of one (size, hist, variant) group run as one batch, padded with no-op steps."""
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    dev = _dev()
+    groups = {}
+    for tr in env_golden["env_traces"]:
+        groups.setdefault((tr["size"], tr["hist"], tr["variant"]), []).append(tr)
+    for (size, hist, variant), trs in groups.items():
+        n = len(trs)
+        polys = [np.array(tr["vertices"]) for tr in trs]
+        images = np.stack([np.stack([oracle_raster.create_shape_mask(p, size)] * 3, axis=2) for p in polys])
+        ds = ReplayDataset(size, hist, images[0], polys[0])
+        env = BatchedPolygonEnv(ds, n, end_token=(variant == "end_token"), max_steps=12, device=dev)
+        st = env.reset(images=images, polygons=polys)
+        for b, tr in enumerate(trs):
+            assert _summary(st[b].double().cpu().numpy()) == tr["reset"]
+        longest = max(len(tr["steps"]) for tr in trs)
+        for k in range(longest):
+            acts = np.array([tr["steps"][min(k, len(tr["steps"]) - 1)]["action"] for tr in trs], np.int32)
+            st, reward, done = env.step(torch.from_numpy(acts).to(dev))
+            for b, tr in enumerate(trs):
+                if k < len(tr["steps"]):
+                    s = tr["steps"][k]
+                    assert reward[b].item() == s["reward"] and bool(done[b]) == s["done"]
+                    assert _summary(st[b].double().cpu().numpy()) == s["state"]
+                    nv = int(env.num_predicted[b])
+                    assert env.predicted_vertices[b, :nv].cpu().numpy().tolist() == s["predicted_vertices"]
+                elif tr["steps"][-1]["done"]:
+                    assert reward[b].item() == 0 and bool(done[b])
+        rew, _, _ = env.terminal_rewards()
+        for b, tr in enumerate(trs):
+            if tr["steps"][-1]["done"]:
+                assert rew[b].item() == tr["steps"][-1]["reward"]
