@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libisg.so")
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
 _f32 = ctypes.c_float
+_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/isg.h one to one
 SIGNATURES = {
@@ -20,6 +21,17 @@ SIGNATURES = {
     "isg_raster_iou": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "isg_shape_mask": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_history_frames": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _int, _vp]),
+    "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
+    "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp,
+                                     _vp, _vp, _ll, _vp, _vp]),
+    "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _int, _int, _int, _int, _int, _vp, _int,
+                                          _vp, _vp, _vp]),
+    "isg_convlstm_dgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _int, _int, _vp,
+                                  _vp]),
+    "isg_convlstm_wgrad_workspace_bytes": (_ll, [_int, _int]),
+    "isg_convlstm_wgrad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _vp,
+                                  _vp, _vp, _vp]),
 }
 
 _lib = None

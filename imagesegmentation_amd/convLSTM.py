@@ -1,0 +1,408 @@
+"""ConvLSTM cell and its stacked recurrence, with the reference's names and call shapes.
+
+* ``ConvLSTMCell(shape, filters, kernel, initializer=None, forget_bias=1.0)`` with ``state_size``,
+  ``output_size`` and ``cell(x, (c, h)) -> (output, LSTMStateTuple(c, h))``     reference convLSTM.py:5-45
+* ``MultiRNNCell([cells])`` + ``dynamic_rnn(cell, inputs, sequence_length, initial_state,
+  time_major=True) -> (outputs, final_state)``   the TensorFlow pieces the reference composes at
+  polyrnn/History2LargeExperiment.py:31-46
+
+Tensors are NHWC torch CUDA tensors.  Variables keep the reference's names and layouts
+(``input_to_state_kernel`` [kh, kw, C, 4F], ``hidden_to_state_kernel`` [kh, kw, F, 4F], ``bias`` [4F],
+gate blocks j|i|f|o) and are float32; ``compute_dtype`` selects float32 (f32 MFMA) or bfloat16 (bf16
+MFMA, float32 accumulation and cell state) for the activations.  ``forget_bias`` is accepted and, as
+in the reference, never used.
+"""
+import collections
+import math
+
+import torch
+
+from . import ops
+
+LSTMStateTuple = collections.namedtuple("LSTMStateTuple", ("c", "h"))
+
+
+def glorot_uniform_(tensor):
+    """TensorFlow's default variable initializer for get_variable (glorot uniform) on an HWIO kernel."""
+    kh, kw, cin, cout = tensor.shape
+    limit = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    with torch.no_grad():
+        return tensor.uniform_(-limit, limit)
+
+
+def _pad_channels(x, cs):
+    c = x.shape[-1]
+    if c == cs:
+        return x.contiguous()
+    out = torch.zeros(x.shape[:-1] + (cs,), dtype=x.dtype, device=x.device)
+    out[..., :c] = x
+    return out
+
+
+class ConvLSTMCell(torch.nn.Module):
+    def __init__(self, shape, filters, kernel, initializer=None, forget_bias=1.0, compute_dtype=torch.float32,
+                 device=None):
+        super().__init__()
+        if list(kernel) != [3, 3]:
+            raise NotImplementedError("the HIP cell implements the reference's 3x3 kernel only")
+        if filters != ops.F_HIDDEN:
+            raise NotImplementedError("the HIP cell implements the reference's 16 filters only")
+        self._kernel = list(kernel)
+        self._filters = int(filters)
+        self._initializer = initializer
+        self._forget_bias = forget_bias  # stored, unused (reference convLSTM.py:15 vs :42)
+        self._shape = list(shape)
+        self.compute_dtype = compute_dtype
+        self._device = device
+        gates = 4 * self._filters
+        self.hidden_to_state_kernel = torch.nn.Parameter(
+            self._init(torch.empty(self._kernel + [self._filters, gates], device=device)))
+        self.bias = torch.nn.Parameter(torch.zeros([gates], device=device))
+        self.input_to_state_kernel = None  # created on first call, when the input channels are known
+        self._packed = None
+        self._packed_key = None
+
+    def _init(self, t):
+        if self._initializer is not None:
+            with torch.no_grad():
+                self._initializer(t)
+            return t
+        return glorot_uniform_(t)
+
+    @property
+    def state_size(self):
+        size = torch.Size(self._shape + [self._filters])
+        return LSTMStateTuple(size, size)
+
+    @property
+    def output_size(self):
+        return torch.Size(self._shape + [self._filters])
+
+    def build(self, channels, device=None):
+        """Creates ``input_to_state_kernel`` for ``channels`` inputs (TensorFlow does this inside
+        the first call through get_variable)."""
+        if self.input_to_state_kernel is None:
+            device = device if device is not None else self.hidden_to_state_kernel.device
+            w = torch.empty(self._kernel + [int(channels), 4 * self._filters], device=device)
+            self.input_to_state_kernel = torch.nn.Parameter(self._init(w))
+        elif self.input_to_state_kernel.shape[2] != channels:
+            raise ValueError("cell was built for %d input channels, got %d" %
+                             (self.input_to_state_kernel.shape[2], channels))
+        return self
+
+    def zero_state(self, batch_size, device=None):
+        device = device if device is not None else self.hidden_to_state_kernel.device
+        shape = [batch_size] + self._shape + [self._filters]
+        return LSTMStateTuple(torch.zeros(shape, dtype=torch.float32, device=device),
+                              torch.zeros(shape, dtype=self.compute_dtype, device=device))
+
+    def packed(self):
+        """Operand images of the current weights; rebuilt whenever a parameter changed in place."""
+        params = (self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype,)
+        if self._packed is None or self._packed_key != key:
+            cs = ops.padded_channels(self.input_to_state_kernel.shape[2], self.compute_dtype)
+            self._packed = ops.PackedWeights(self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias, cs,
+                                             self.compute_dtype)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x, h, scope=None):
+        """One step: x [B, H, W, C]; h = (c, h) state tuple.  Returns (output, LSTMStateTuple(c, h))."""
+        previous_memory, previous_output = h
+        self.build(x.shape[-1], x.device)
+        new_h, new_c = _CellFunction.apply(x, previous_memory, previous_output, self.input_to_state_kernel,
+                                           self.hidden_to_state_kernel, self.bias, self)
+        return new_h, LSTMStateTuple(new_c, new_h)
+
+
+class _CellFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c_prev, h_prev, w_x, w_h, bias, cell):
+        dt = cell.compute_dtype
+        packed = cell.packed()
+        xs = _pad_channels(x.to(dt), packed.cs)
+        hp = h_prev.to(dt).contiguous()
+        cp = c_prev.to(torch.float32).contiguous()
+        h, c, gates = ops.cell_fwd(xs, hp, cp, packed)
+        ctx.save_for_backward(xs, hp, cp, c, gates)
+        ctx.packed = packed
+        ctx.in_dtypes = (x.dtype, c_prev.dtype, h_prev.dtype)
+        ctx.c_real = x.shape[-1]
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        xs, hp, cp, c, gates = ctx.saved_tensors
+        packed = ctx.packed
+        dt = packed.dtype
+        B, H, W, _ = xs.shape
+        F = packed.f
+        dh = dh.to(dt).contiguous() if dh is not None else None
+        dc = dc.to(torch.float32).contiguous() if dc is not None else None
+        dy, dc_prev = ops.pointwise_bwd(gates, cp, c, dh, H * W * F, None, dc)
+        dw_x = torch.zeros([3, 3, ctx.c_real, 4 * F], dtype=torch.float32, device=xs.device)
+        dw_h = torch.zeros([3, 3, F, 4 * F], dtype=torch.float32, device=xs.device)
+        dbias = torch.zeros([4 * F], dtype=torch.float32, device=xs.device)
+        ops.wgrad(xs, hp, dy, ctx.c_real, dw_x, dw_h, dbias, accumulate=False)
+        dx = torch.empty_like(xs)
+        dh_prev = torch.empty_like(hp)
+        ops.dgrad(dy, packed, dh_prev, dx=dx, dx_channels=packed.cs)
+        xd, cd, hd = ctx.in_dtypes
+        return dx[..., :ctx.c_real].to(xd), dc_prev.to(cd), dh_prev.to(hd), dw_x, dw_h, dbias, None
+
+
+class MultiRNNCell(torch.nn.Module):
+    """Stack of cells: the output of cell l is the input of cell l+1 (tf.contrib.rnn.MultiRNNCell)."""
+
+    def __init__(self, cells):
+        super().__init__()
+        self.cells = torch.nn.ModuleList(cells)
+
+    @property
+    def state_size(self):
+        return tuple(c.state_size for c in self.cells)
+
+    @property
+    def output_size(self):
+        return self.cells[-1].output_size
+
+    def zero_state(self, batch_size, device=None):
+        return tuple(c.zero_state(batch_size, device) for c in self.cells)
+
+    def build(self, channels, device=None):
+        for cell in self.cells:
+            cell.build(channels, device)
+            channels = cell._filters
+        return self
+
+    def forward(self, x, state):
+        new_state = []
+        for cell, s in zip(self.cells, state):
+            x, s2 = cell(x, s)
+            new_state.append(s2)
+        return x, tuple(new_state)
+
+
+class SequenceInput:
+    """Where the stacked recurrence takes its layer-0 input from.
+
+    Either ``x_seq`` [T, B, H, W, C] (generic, time-major), or the reference's tiled form
+    (polyrnn/History2LargeExperiment.py:24-25): ``static`` [B, H, W, Cf] features repeated at every
+    step, concatenated with that step's history frames, given densely (``hist_dense``
+    [B, T, H, W, hist]) or as vertex points (``hist_points`` int32 [B, T, hist, 2], x < 0 = empty).
+    The tiled tensor is never materialised: one [B, H, W, Cs] buffer is reused and only its history
+    channels are rewritten per step.
+    """
+
+    def __init__(self, x_seq=None, static=None, hist_dense=None, hist_points=None):
+        self.x_seq, self.static, self.hist_dense, self.hist_points = x_seq, static, hist_dense, hist_points
+        if x_seq is not None:
+            self.T, self.B, self.H, self.W, self.C = x_seq.shape
+            self.hist = 0
+        else:
+            self.B, self.H, self.W, cf = static.shape
+            if hist_dense is not None:
+                self.T, self.hist = hist_dense.shape[1], hist_dense.shape[4]
+            else:
+                self.T, self.hist = hist_points.shape[1], hist_points.shape[2]
+            self.C = cf + self.hist
+        self._buf = None
+        self._buf_t = None
+
+    def prepare(self, dtype, cs):
+        self.dtype, self.cs = dtype, cs
+        if self.x_seq is not None:
+            return
+        cf = self.static.shape[-1]
+        self._buf = torch.zeros([self.B, self.H, self.W, cs], dtype=dtype, device=self.static.device)
+        self._buf[..., :cf] = self.static.to(dtype)
+        if self.hist_points is not None:
+            self.hist_points = self.hist_points.to(torch.int32).contiguous()
+
+    def get(self, t):
+        """[B, H, W, Cs] input of step t, valid until the next call."""
+        if self.x_seq is not None:
+            return _pad_channels(self.x_seq[t].to(self.dtype), self.cs)
+        if self._buf_t == t or self.hist == 0:
+            return self._buf
+        cf = self.static.shape[-1]
+        if self.hist_dense is not None:
+            self._buf[..., cf:cf + self.hist] = self.hist_dense[:, t].to(self.dtype)
+        else:
+            from . import _lib
+            pts = self.hist_points[:, t].contiguous()
+            rc = _lib.lib().isg_history_frames(_lib.ptr(pts), self.B, self.H, self.hist, ops.dtype_code(self.dtype),
+                                               _lib.ptr(self._buf), self.cs, cf, _lib.current_stream())
+            _lib.check(rc, "isg_history_frames")
+        self._buf_t = t
+        return self._buf
+
+
+def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
+    """Shared by the autograd function and the no-grad decode path."""
+    L, T = len(cells), seq.T
+    dt = cells[0].compute_dtype
+    B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
+    dev = init_state[0][0].device
+    packed = [c.packed() for c in cells]
+    seq.prepare(dt, packed[0].cs)
+    n_keep = T + 1 if save else 2
+    Hs = [torch.empty([n_keep, B, H, W, F], dtype=dt, device=dev) for _ in range(L)]
+    Cs = [torch.empty([n_keep, B, H, W, F], dtype=torch.float32, device=dev) for _ in range(L)]
+    Gs = [torch.empty([T, B, H, W, F, 4], dtype=dt, device=dev) for _ in range(L)] if save else None
+    for l in range(L):
+        Cs[l][0].copy_(init_state[l][0])
+        Hs[l][0].copy_(init_state[l][1])
+    out = torch.zeros([B, T, H, W, F], dtype=dt, device=dev)
+    cur = 0
+    for t in range(t_run):
+        x = seq.get(t)
+        nxt = cur + 1 if save else 1 - cur
+        for l in range(L):
+            ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
+                         out=out[:, t] if l == L - 1 else None, out_batch_stride=T * H * W * F,
+                         save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None)
+            x = Hs[l][nxt]
+        cur = nxt
+    final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
+    return out, final, (Hs, Cs, Gs, packed)
+
+
+class _SequenceFunction(torch.autograd.Function):
+    """MultiRNNCell + dynamic_rnn as ONE autograd node: T*L fused cell launches forward, and the
+    hand-written reverse sweep (pointwise, weight-gradient and data-gradient kernels) backward."""
+
+    @staticmethod
+    def forward(ctx, multi, seq, durations_dev, t_run, n_state, *tensors):
+        # tensors = [layer-0 differentiable input] + [c0, h0] * L + [w_x, w_h, bias] * L
+        cells = list(multi.cells)
+        L = len(cells)
+        init_state = [(tensors[1 + 2 * l], tensors[2 + 2 * l]) for l in range(L)]
+        out, final, (Hs, Cs, Gs, packed) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, True)
+        ctx.multi, ctx.seq, ctx.durations_dev, ctx.t_run = multi, seq, durations_dev, t_run
+        ctx.saved = (Hs, Cs, Gs, packed)
+        ctx.in_dtype = tensors[0].dtype
+        ctx.state_dtypes = [(c.dtype, h.dtype) for c, h in init_state]
+        flat = [out]
+        for c, h in final:
+            flat += [c.clone(), h.clone()]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, d_out, *d_final):
+        cells = list(ctx.multi.cells)
+        L = len(cells)
+        seq, durations_dev, t_run = ctx.seq, ctx.durations_dev, ctx.t_run
+        Hs, Cs, Gs, packed = ctx.saved
+        dt = cells[0].compute_dtype
+        B, H, W, F, T = seq.B, seq.H, seq.W, cells[0]._filters, seq.T
+        dev = Hs[0].device
+        d_out = d_out.to(dt).contiguous() if d_out is not None else torch.zeros([B, T, H, W, F], dtype=dt, device=dev)
+        dc_state, dh_state = [], []
+        for l in range(L):
+            dc, dh = d_final[2 * l], d_final[2 * l + 1]
+            dc_state.append(dc.to(torch.float32).clone().contiguous() if dc is not None else
+                            torch.zeros([B, H, W, F], dtype=torch.float32, device=dev))
+            dh_state.append(dh.to(dt).clone().contiguous() if dh is not None else
+                            torch.zeros([B, H, W, F], dtype=dt, device=dev))
+        grads = []
+        for cell in cells:
+            grads.append((torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32),
+                          torch.zeros_like(cell.hidden_to_state_kernel, dtype=torch.float32),
+                          torch.zeros_like(cell.bias, dtype=torch.float32)))
+        dy = torch.empty([B, H, W, F, 4], dtype=dt, device=dev)
+        dx_mid = torch.empty([B, H, W, F], dtype=dt, device=dev)
+        cs0 = packed[0].cs
+        if seq.x_seq is not None:
+            d_in = torch.zeros([T, B, H, W, cs0], dtype=dt, device=dev)
+            dx0_channels = cs0
+        else:
+            cf = seq.static.shape[-1]
+            d_in = torch.zeros([B, H, W, cf], dtype=dt, device=dev)
+            dx0_channels = cf
+        seq._buf_t = None
+        for t in reversed(range(t_run)):
+            x0 = seq.get(t)
+            for l in reversed(range(L)):
+                x_in = x0 if l == 0 else Hs[l - 1][t + 1]
+                if l == L - 1:
+                    above, stride = d_out[:, t], T * H * W * F
+                else:
+                    above, stride = dx_mid, H * W * F
+                ops.pointwise_bwd(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l],
+                                  durations_dev, t, dy=dy, dc_prev=dc_state[l])
+                c_real = cells[l].input_to_state_kernel.shape[2]
+                ops.wgrad(x_in, Hs[l][t], dy, c_real, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t)
+                if l > 0:
+                    ops.dgrad(dy, packed[l], dh_state[l], dx=dx_mid, dx_channels=F, durations=durations_dev, t=t)
+                elif seq.x_seq is not None:
+                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in[t], dx_channels=dx0_channels,
+                              durations=durations_dev, t=t)
+                elif dx0_channels % 4 == 0:
+                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in, dx_channels=dx0_channels, dx_accumulate=True,
+                              durations=durations_dev, t=t)
+                else:
+                    raise NotImplementedError("static feature channels must be a multiple of 4")
+        if seq.x_seq is not None:
+            d_input = d_in[..., :seq.C].to(ctx.in_dtype)
+        else:
+            d_input = d_in.to(ctx.in_dtype)
+        result = [None, None, None, None, None, d_input]
+        for l in range(L):
+            cd, hd = ctx.state_dtypes[l]
+            result += [dc_state[l].to(cd), dh_state[l].to(hd)]
+        for l in range(L):
+            result += list(grads[l])
+        return tuple(result)
+
+
+def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True):
+    """``tf.nn.dynamic_rnn`` for a ``MultiRNNCell`` (or a single cell) of ConvLSTM cells.
+
+    inputs: a time-major tensor [T, B, H, W, C] (``time_major=False``: [B, T, H, W, C]) or a
+    ``SequenceInput``.  sequence_length: int array/tensor [B] or None.  Past a sample's length the
+    emitted output is zero and its state is carried through unchanged.
+    Returns (outputs, final_state); outputs are [T, B, H, W, F] when time_major else [B, T, H, W, F].
+    """
+    multi = cell if isinstance(cell, MultiRNNCell) else MultiRNNCell([cell])
+    if isinstance(inputs, SequenceInput):
+        seq = inputs
+        diff_input = seq.x_seq if seq.x_seq is not None else seq.static
+    else:
+        x_seq = inputs if time_major else inputs.transpose(0, 1)
+        seq = SequenceInput(x_seq=x_seq)
+        diff_input = x_seq
+    dev = diff_input.device
+    multi.build(seq.C, dev)
+    T, B = seq.T, seq.B
+    if sequence_length is None:
+        durations_dev, t_run = None, T
+    else:
+        if torch.is_tensor(sequence_length):
+            host = sequence_length.detach().cpu()
+            t_run = int(host.max()) if host.numel() else 0
+            durations_dev = sequence_length.to(device=dev, dtype=torch.int32).contiguous()
+        else:
+            import numpy as np
+            host = np.asarray(sequence_length)
+            t_run = int(host.max()) if host.size else 0
+            durations_dev = torch.as_tensor(host.astype(np.int32), device=dev)
+        t_run = max(0, min(t_run, T))
+    if initial_state is None:
+        initial_state = multi.zero_state(B, dev)
+    elif not isinstance(initial_state[0], (tuple, list)):
+        initial_state = (initial_state,)
+    tensors = [diff_input]
+    for c, h in initial_state:
+        tensors += [c, h]
+    for c in multi.cells:
+        tensors += [c.input_to_state_kernel, c.hidden_to_state_kernel, c.bias]
+    flat = _SequenceFunction.apply(multi, seq, durations_dev, t_run, len(multi.cells), *tensors)
+    out = flat[0]
+    final = tuple(LSTMStateTuple(flat[1 + 2 * l], flat[2 + 2 * l]) for l in range(len(multi.cells)))
+    if time_major:
+        out = out.transpose(0, 1)
+    if not isinstance(cell, MultiRNNCell):
+        final = final[0]
+    return out, final

@@ -1,0 +1,895 @@
+// ConvLSTM cell kernels for gfx950: fused gate convolution (implicit GEMM on MFMA) + gate math,
+// and the three backward pieces (pointwise gate backward, data gradient, weight gradient).
+//
+// Orientation of every MFMA product here:  D[row][pixel] = sum_k A[row][k] * B[k][pixel]
+//   A = packed weights (rows = gate columns or input channels), B = activations staged in LDS,
+//   so one lane owns ONE pixel column of the 32x32 result and, through the D register map
+//   row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), groups of 4 consecutive rows.
+// The forward weight image orders its 64 gate rows so that those 4 consecutive rows are the four
+// gates (j, i, f, o) of one channel: the LSTM update is then lane-local and each lane stores 8
+// contiguous channels of its pixel.
+//
+// Tile: 8 x 32 output pixels per 256-thread workgroup (4 waves, 64 pixels x 64 rows each), input
+// tile with a 1-pixel halo staged in LDS once and reused by all 9 taps; workgroups are persistent
+// over tiles so the weight image is loaded into LDS once per workgroup (bf16) or streamed from L2
+// (f32, whose MFMA is 16x slower and needs no LDS residency).
+#include <hip/hip_bf16.h>
+
+#include "isg_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int TH = 8, TW = 32;             // output tile
+constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int NPX = HALO_W * HALO_H;       // staged input pixels per tile
+constexpr int F_ = 16;                     // hidden channels (every runnable reference net)
+constexpr int NG = 4 * F_;                 // gate columns
+constexpr int kWgradMaxBlocks = 256;       // partial-sum slabs per weight-gradient launch
+
+template <typename T>
+struct Tr;
+
+template <>
+struct Tr<float> {
+    static constexpr int KG = 1;      // k values a lane feeds per MFMA
+    static constexpr int CHUNK = 4;   // elements per 16-byte staging chunk
+    static constexpr int PAD = 4;     // bytes added to an LDS pixel row (bank spread)
+    static constexpr int DTYPE = ISG_F32;
+    static constexpr bool W_IN_LDS = false;
+    using frag = float;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+    static __device__ __forceinline__ float ex(float v) { return expf(v); }
+};
+
+template <>
+struct Tr<__bf16> {
+    static constexpr int KG = 8;
+    static constexpr int CHUNK = 8;
+    static constexpr int PAD = 16;
+    static constexpr int DTYPE = ISG_BF16;
+    static constexpr bool W_IN_LDS = true;
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
+    static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
+    static __device__ __forceinline__ float ex(float v) { return __expf(v); }
+};
+
+template <typename T>
+__device__ __forceinline__ float sigmoid_t(float z) {
+    return 1.0f / (1.0f + Tr<T>::ex(-z));
+}
+template <typename T>
+__device__ __forceinline__ float tanh_t(float z) {
+    // 1 - 2 / (exp(2z) + 1); saturates cleanly at +-1 for large |z|
+    return 1.0f - 2.0f / (Tr<T>::ex(2.0f * z) + 1.0f);
+}
+
+// Reference gate column (j|i|f|o blocks of F) held by row R of the forward weight image.
+__host__ __device__ inline int fwd_row_to_col(int R) {
+    const int t = R >> 5, r = R & 31;
+    const int gate = r & 3, hh = (r >> 2) & 1, a = r >> 3;
+    return gate * F_ + 8 * hh + 4 * t + a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+// Image layout for both kinds: [k-step s][row tile t][lane 0..63][KG] with the lane's row
+// R = 32 t + (lane & 31) and its k-group g = 2 s + (lane >> 5); k-group g covers KG consecutive
+// channels of one tap: tap = g / GPT, first channel = (g % GPT) * KG.
+//   forward image: rows = 64 permuted gate columns, channels = [x (Cs) | h (F)]
+//   dgrad image  : rows = input channels [x (Cs) | h (F)] padded to 32*MT, channels of a tap = the
+//                  64 gate columns in the kernels' (channel, gate) order; taps are flipped.
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* __restrict__ w_h, int C, int Cs,
+                                    int kind, int MT, T* __restrict__ out, long long total) {
+    constexpr int KG = Tr<T>::KG;
+    const int cpt = kind == 0 ? Cs + F_ : NG;  // channels per tap on the K side
+    const int gpt = cpt / KG;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % KG);
+        long long r = idx / KG;
+        const int lane = (int)(r % 64);
+        r /= 64;
+        const int t = (int)(r % MT);
+        const int s = (int)(r / MT);
+        const int R = 32 * t + (lane & 31);
+        const int g = 2 * s + (lane >> 5);
+        const int tap = g / gpt;
+        const int kc = (g - tap * gpt) * KG + j;  // channel within the tap, K side
+        float v = 0.0f;
+        if (tap < 9) {
+            if (kind == 0) {
+                const int col = fwd_row_to_col(R);
+                if (kc < C) v = w_x[((size_t)tap * C + kc) * NG + col];
+                else if (kc >= Cs) v = w_h[((size_t)tap * F_ + (kc - Cs)) * NG + col];
+            } else {
+                const int ch = kc >> 2, gate = kc & 3;  // dY channel order: [channel][gate]
+                const int col = gate * F_ + ch;
+                const int ftap = 8 - tap;               // flipped tap
+                if (R < C) v = w_x[((size_t)ftap * C + R) * NG + col];
+                else if (R >= Cs && R < Cs + F_) v = w_h[((size_t)ftap * F_ + (R - Cs)) * NG + col];
+            }
+        }
+        out[idx] = Tr<T>::from_f(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces of the two convolution-shaped kernels
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const void* in0;  // [B,H,W,c0]
+    const void* in1;  // [B,H,W,c1] or null (c1 = 0)
+    int c0, c1;
+    int B, H, W;
+    const void* wimg;  // packed image
+    int spt;           // k-steps per tap
+    int tiles_x, tiles_y;
+    const int* durations;  // [B] or null
+    int t;                 // current time step (compared with durations)
+    // LSTM epilogue
+    const float* bias;     // [4F] reference order
+    const float* c_prev;   // [B,H,W,F]
+    float* c_out;          // [B,H,W,F]
+    void* h_out;           // [B,H,W,F]
+    void* out;             // masked output or null; sample stride out_bstride elements
+    long long out_bstride;
+    void* gates;           // [B,H,W,F,4] (g,i,f,o) or null
+    // dgrad epilogue
+    void* dx;              // [B,H,W,dx_cstride] or null
+    int dx_channels, dx_cstride, dx_accumulate;
+    void* dh_prev;         // [B,H,W,F]; left untouched for a masked sample (state gradient passes through)
+    int row_split;         // rows [0, row_split) -> dx, [row_split, row_split + F) -> dh_prev
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_tile(const void* in0, const void* in1, int c0, int c1, int H, int W, int b,
+                                           int ty0, int tx0, char* lds_in, int pstride) {
+    constexpr int CH = Tr<T>::CHUNK;
+    const int n0 = c0 / CH, nch = n0 + c1 / CH;
+    for (int idx = threadIdx.x; idx < NPX * nch; idx += kThreads) {
+        const int px = idx / nch, ch = idx - px * nch;
+        const int hy = px / HALO_W, hx = px - hy * HALO_W;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t pixel = ((size_t)b * H + gy) * W + gx;
+            const T* src = ch < n0 ? static_cast<const T*>(in0) + pixel * c0 + ch * CH
+                                   : static_cast<const T*>(in1) + pixel * c1 + (ch - n0) * CH;
+            v = *reinterpret_cast<const uint4*>(src);
+        }
+        char* dst = lds_in + px * pstride + ch * 16;
+        if constexpr (Tr<T>::PAD % 16 == 0) {
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+    }
+}
+
+// acc[t][pt] += sum over 9 taps and all channel groups.  Wave handles tile rows 2*wave, 2*wave+1.
+template <typename T, int MT>
+__device__ __forceinline__ void conv_mainloop(const char* lds_in, int pstride, const char* lds_w, const T* gw, int spt,
+                                              f32x16 (&acc)[MT][2]) {
+    using frag = typename Tr<T>::frag;
+    constexpr int KG = Tr<T>::KG;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, half = lane >> 5;
+    const char* b_base = lds_in + ((2 * wave) * HALO_W + p) * pstride + half * KG * (int)sizeof(T);
+    int s = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const char* b_tap = b_base + (dy * HALO_W + dx) * pstride;
+        for (int q = 0; q < spt; ++q, ++s) {
+            frag a[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                if constexpr (Tr<T>::W_IN_LDS)
+                    a[t] = *reinterpret_cast<const frag*>(lds_w + ((size_t)(s * MT + t) * 64 + lane) * sizeof(frag));
+                else
+                    a[t] = *reinterpret_cast<const frag*>(gw + ((size_t)(s * MT + t) * 64 + lane) * KG);
+            }
+            const frag b0 = *reinterpret_cast<const frag*>(b_tap + q * 2 * KG * (int)sizeof(T));
+            const frag b1 = *reinterpret_cast<const frag*>(b_tap + HALO_W * pstride + q * 2 * KG * (int)sizeof(T));
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t][0] = Tr<T>::mma(a[t], b0, acc[t][0]);
+                acc[t][1] = Tr<T>::mma(a[t], b1, acc[t][1]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(dst) = o;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* src, float (&v)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src);
+        v[0] = x[0], v[1] = x[1], v[2] = x[2], v[3] = x[3];
+    } else {
+        const bf16x4 x = *reinterpret_cast<const bf16x4*>(src);
+        v[0] = (float)x[0], v[1] = (float)x[1], v[2] = (float)x[2], v[3] = (float)x[3];
+    }
+}
+
+// MODE 0: LSTM forward (rows = 64 permuted gate columns).  MODE 1: data gradient (rows = channels).
+template <typename T, int MT, int MODE>
+__global__ __launch_bounds__(kThreads) void conv3x3_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cpt = p.c0 + p.c1;
+    const int pstride = cpt * (int)sizeof(T) + Tr<T>::PAD;
+    const size_t wbytes = Tr<T>::W_IN_LDS ? (size_t)9 * p.spt * MT * 64 * sizeof(typename Tr<T>::frag) : 0;
+    char* lds_w = smem;
+    char* lds_in = smem + wbytes;
+    float* lds_bias = reinterpret_cast<float*>(lds_in + ((NPX * pstride + 15) & ~15));
+
+    if constexpr (Tr<T>::W_IN_LDS) {
+        const uint4* src = static_cast<const uint4*>(p.wimg);
+        uint4* dst = reinterpret_cast<uint4*>(lds_w);
+        for (size_t i = threadIdx.x; i < wbytes / 16; i += kThreads) dst[i] = src[i];
+    }
+    if (MODE == 0 && threadIdx.x < NG) lds_bias[threadIdx.x] = p.bias[threadIdx.x];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px_l = lane & 31, half = lane >> 5;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img;
+        const int rem = tile - b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+        const bool live = p.durations == nullptr || p.t < p.durations[b];
+
+        if (!live) {
+            // dynamic_rnn past the sequence end: state copied through, emitted output zero
+            if (MODE == 0) {
+                for (int i = threadIdx.x; i < TH * TW * (F_ / 4); i += kThreads) {
+                    const int q4 = i & 3, pix = i >> 2;
+                    const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
+                    if (gy < p.H && gx < p.W) {
+                        const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
+                        const size_t o = pixel * F_ + q4 * 4;
+                        *reinterpret_cast<f32x4*>(p.c_out + o) = *reinterpret_cast<const f32x4*>(p.c_prev + o);
+                        float hv[4];
+                        load4(static_cast<const T*>(p.in1) + o, hv);
+                        store4(static_cast<T*>(p.h_out) + o, hv);
+                        if (p.out) {
+                            const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                            const size_t oo = (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + q4 * 4;
+                            store4(static_cast<T*>(p.out) + oo, z);
+                        }
+                    }
+                }
+                continue;  // (block-uniform branch: no barrier is skipped by part of the block)
+            }
+            // MODE 1: dY of a masked sample is all zero, so the convolution adds nothing and
+            // dh_prev keeps the incoming state gradient; only dx needs defining when not accumulating.
+            if (p.dx && !p.dx_accumulate) {
+                for (int i = threadIdx.x; i < TH * TW * (p.dx_channels / 4); i += kThreads) {
+                    const int nq = p.dx_channels / 4;
+                    const int q4 = i % nq, pix = i / nq;
+                    const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
+                    if (gy < p.H && gx < p.W) {
+                        const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
+                        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                        store4(static_cast<T*>(p.dx) + pixel * p.dx_cstride + q4 * 4, z);
+                    }
+                }
+            }
+            continue;
+        }
+
+        __syncthreads();  // previous tile's LDS reads are done (and the weight image is in place)
+        stage_tile<T>(p.in0, p.in1, p.c0, p.c1, p.H, p.W, b, ty0, tx0, lds_in, pstride);
+        __syncthreads();
+
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
+        conv_mainloop<T, MT>(lds_in, pstride, lds_w, static_cast<const T*>(p.wimg), p.spt, acc);
+
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
+            if (gy >= p.H || gx >= p.W) continue;
+            const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
+            if constexpr (MODE == 0) {
+                static_assert(MODE != 0 || MT == 2, "forward image has 64 rows");
+                const size_t so = pixel * F_ + 8 * half;
+                float cp[8];
+                {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.c_prev + so);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.c_prev + so + 4);
+                    cp[0] = c0[0], cp[1] = c0[1], cp[2] = c0[2], cp[3] = c0[3];
+                    cp[4] = c1[0], cp[5] = c1[1], cp[6] = c1[2], cp[7] = c1[3];
+                }
+                float hn[8], cn[8], gs[32];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int cl = 4 * t + a, ch = 8 * half + cl;
+                        const float g = tanh_t<T>(acc[t][pt][4 * a + 0] + lds_bias[ch]);
+                        const float ig = sigmoid_t<T>(acc[t][pt][4 * a + 1] + lds_bias[F_ + ch]);
+                        const float fg = sigmoid_t<T>(acc[t][pt][4 * a + 2] + lds_bias[2 * F_ + ch]);
+                        const float og = sigmoid_t<T>(acc[t][pt][4 * a + 3] + lds_bias[3 * F_ + ch]);
+                        const float c = fg * cp[cl] + ig * g;
+                        cn[cl] = c;
+                        hn[cl] = og * tanh_t<T>(c);
+                        gs[4 * cl + 0] = g, gs[4 * cl + 1] = ig, gs[4 * cl + 2] = fg, gs[4 * cl + 3] = og;
+                    }
+                *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+                *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
+                {
+                    const float h0[4] = {hn[0], hn[1], hn[2], hn[3]}, h1[4] = {hn[4], hn[5], hn[6], hn[7]};
+                    store4(static_cast<T*>(p.h_out) + so, h0);
+                    store4(static_cast<T*>(p.h_out) + so + 4, h1);
+                    if (p.out) {
+                        const size_t oo = (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half;
+                        store4(static_cast<T*>(p.out) + oo, h0);
+                        store4(static_cast<T*>(p.out) + oo + 4, h1);
+                    }
+                }
+                if (p.gates) {
+                    T* gd = static_cast<T*>(p.gates) + pixel * NG + 32 * half;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float v[4] = {gs[4 * k], gs[4 * k + 1], gs[4 * k + 2], gs[4 * k + 3]};
+                        store4(gd + 4 * k, v);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int cc0 = 32 * t + 8 * a + 4 * half;
+                        float v[4] = {acc[t][pt][4 * a], acc[t][pt][4 * a + 1], acc[t][pt][4 * a + 2],
+                                      acc[t][pt][4 * a + 3]};
+                        if (cc0 < p.row_split) {  // x part of the concatenated input
+                            if (p.dx && cc0 < p.dx_channels) {
+                                T* d = static_cast<T*>(p.dx) + pixel * p.dx_cstride + cc0;
+                                if (p.dx_accumulate) {
+                                    float old[4];
+                                    load4(d, old);
+                                    v[0] += old[0], v[1] += old[1], v[2] += old[2], v[3] += old[3];
+                                }
+                                store4(d, v);
+                            }
+                        } else if (cc0 < p.row_split + F_) {
+                            store4(static_cast<T*>(p.dh_prev) + pixel * F_ + (cc0 - p.row_split), v);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise gate backward
+// ---------------------------------------------------------------------------------------------
+struct PointwiseParams {
+    const void* gates;     // [B,H,W,F,4] (g,i,f,o)
+    const float* c_prev;   // [B,H,W,F]
+    const float* c_cur;    // [B,H,W,F]
+    const void* dh_above;  // grad of h as the layer's OUTPUT, sample stride dh_above_bstride, or null
+    long long dh_above_bstride;
+    const void* dh_state;  // grad of h as carried STATE [B,H,W,F], or null
+    const float* dc_state; // [B,H,W,F] or null
+    float* dc_prev;        // [B,H,W,F] (may alias dc_state)
+    void* dy;              // [B,H,W,F,4] pre-activation grads, (channel, gate) order
+    const int* durations;
+    int t, B, HW;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams p) {
+    const long long total = (long long)p.B * p.HW * (F_ / 4);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int q4 = (int)(idx & 3);
+        const long long pixel = idx >> 2;
+        const int b = (int)(pixel / p.HW);
+        const size_t so = (size_t)pixel * F_ + q4 * 4;
+        const bool live = p.durations == nullptr || p.t < p.durations[b];
+        float dc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.dc_state) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.dc_state + so);
+            dc[0] = v[0], dc[1] = v[1], dc[2] = v[2], dc[3] = v[3];
+        }
+        T* dy = static_cast<T*>(p.dy) + (size_t)pixel * NG + q4 * 16;
+        if (!live) {
+            const float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store4(dy + 4 * k, z);
+            *reinterpret_cast<f32x4*>(p.dc_prev + so) = f32x4{dc[0], dc[1], dc[2], dc[3]};
+            continue;
+        }
+        float dh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.dh_above) {
+            float v[4];
+            load4(static_cast<const T*>(p.dh_above) + (size_t)b * p.dh_above_bstride +
+                      (size_t)(pixel - (long long)b * p.HW) * F_ + q4 * 4, v);
+            dh[0] += v[0], dh[1] += v[1], dh[2] += v[2], dh[3] += v[3];
+        }
+        if (p.dh_state) {
+            float v[4];
+            load4(static_cast<const T*>(p.dh_state) + so, v);
+            dh[0] += v[0], dh[1] += v[1], dh[2] += v[2], dh[3] += v[3];
+        }
+        const f32x4 cpv = *reinterpret_cast<const f32x4*>(p.c_prev + so);
+        const f32x4 ccv = *reinterpret_cast<const f32x4*>(p.c_cur + so);
+        float dcp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gv[4];
+            load4(static_cast<const T*>(p.gates) + (size_t)pixel * NG + q4 * 16 + 4 * k, gv);
+            const float g = gv[0], ig = gv[1], fg = gv[2], og = gv[3];
+            const float tc = tanh_t<T>(ccv[k]);
+            const float d_o = dh[k] * tc;
+            const float dct = dc[k] + dh[k] * og * (1.0f - tc * tc);
+            const float out[4] = {dct * ig * (1.0f - g * g), dct * g * ig * (1.0f - ig),
+                                  dct * cpv[k] * fg * (1.0f - fg), d_o * og * (1.0f - og)};
+            store4(dy + 4 * k, out);
+            dcp[k] = dct * fg;
+        }
+        *reinterpret_cast<f32x4*>(p.dc_prev + so) = f32x4{dcp[0], dcp[1], dcp[2], dcp[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  slab[tap][cc][col] = sum_pixels XH[pixel + tap][cc] * dY[pixel][col]
+// ---------------------------------------------------------------------------------------------
+struct WgradParams {
+    const void* in0;  // x [B,H,W,c0]
+    const void* in1;  // h_prev [B,H,W,F]
+    int c0, c1;
+    const void* dy;   // [B,H,W,64] (channel, gate) order
+    int B, H, W, tiles_x, tiles_y;
+    const int* durations;
+    int t;
+    float* slab;       // [gridDim.x][9][MT*32][64]
+    float* bias_slab;  // [gridDim.x][64]
+};
+
+template <typename T, int MT>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int NSLOT = MT == 2 ? 9 : 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cpt = p.c0 + p.c1;
+    const int pstride = cpt * (int)sizeof(T) + Tr<T>::PAD;
+    const int dstride = NG * (int)sizeof(T) + Tr<T>::PAD;
+    char* lds_in = smem;
+    char* lds_dy = smem + ((NPX * pstride + 15) & ~15);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    // work split: MT == 2 -> (mt, nt) = (wave >> 1, wave & 1), all 9 taps
+    //             MT == 1 -> nt = wave & 1, taps 0..4 (wave < 2) or 5..8 (+ one idle slot)
+    const int mt = MT == 2 ? (wave >> 1) : 0;
+    const int nt = wave & 1;
+    const int tap0 = MT == 2 ? 0 : (wave >> 1) * 5;
+    const bool does_bias = MT == 2 ? (mt == 0) : (wave < 2);
+
+    f32x16 acc[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img;
+        const int rem = tile - b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+        if (p.durations != nullptr && p.t >= p.durations[b]) continue;  // dY is zero there
+
+        __syncthreads();
+        stage_tile<T>(p.in0, p.in1, p.c0, p.c1, p.H, p.W, b, ty0, tx0, lds_in, pstride);
+        {
+            constexpr int CH = Tr<T>::CHUNK;
+            constexpr int nch = NG / CH;
+            for (int idx = threadIdx.x; idx < TH * TW * nch; idx += kThreads) {
+                const int px = idx / nch, ch = idx - px * nch;
+                const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (gy < p.H && gx < p.W)
+                    v = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.dy) +
+                                                        (((size_t)b * p.H + gy) * p.W + gx) * NG + ch * CH);
+                char* dst = lds_dy + px * dstride + ch * 16;
+                if constexpr (Tr<T>::PAD % 16 == 0) {
+                    *reinterpret_cast<uint4*>(dst) = v;
+                } else {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+                    d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                }
+            }
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            // k-step = 16 consecutive pixels of one tile row; operands come out of the pixel-major
+            // LDS images through the transposing read (4 pixels x 16 channels per 16-lane group).
+            const int li = lane & 15, g16 = lane >> 4;
+            const int q = li >> 2, pp = li & 3;
+            const int csub = 16 * (g16 & 1) + 4 * pp;  // channel offset inside the 32-row tile
+            for (int ks = 0; ks < 16; ++ks) {
+                const int r = ks >> 1, x0 = (ks & 1) * 16;
+                const int pj = x0 + 8 * half + q;  // this lane's pixel (first read; +4 for the second)
+                bf16x8 bfrag;
+                {
+                    const char* a0 = lds_dy + (r * TW + pj) * dstride + (32 * nt + csub) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * dstride));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bfrag = __builtin_bit_cast(bf16x8, both);
+                }
+                if (does_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)bfrag[j];
+                }
+#pragma unroll
+                for (int i = 0; i < NSLOT; ++i) {
+                    const int tap = tap0 + i;
+                    if (tap < 9) {
+                        const int dy = tap / 3, dx = tap - dy * 3;
+                        const char* a0 = lds_in + ((r + dy) * HALO_W + pj + dx) * pstride + (32 * mt + csub) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(a0));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(a0 + 4 * pstride));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag,
+                                                                         acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // f32: one pixel per lane half per MFMA; rows/cols are contiguous in the pixel-major images
+            const int rc = lane & 31;
+            for (int ks = 0; ks < TH * TW / 2; ++ks) {
+                const int pix = 2 * ks + half;
+                const int r = pix / TW, x = pix & (TW - 1);
+                const float bv = *reinterpret_cast<const float*>(lds_dy + pix * dstride + (32 * nt + rc) * 4);
+                if (does_bias) bsum += bv;
+#pragma unroll
+                for (int i = 0; i < NSLOT; ++i) {
+                    const int tap = tap0 + i;
+                    if (tap < 9) {
+                        const int dy = tap / 3, dx = tap - dy * 3;
+                        const float av = *reinterpret_cast<const float*>(
+                            lds_in + ((r + dy) * HALO_W + x + dx) * pstride + (32 * mt + rc) * 4);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // write this workgroup's partial sums
+    float* slab = p.slab + (size_t)blockIdx.x * 9 * (MT * 32) * NG;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int tap = tap0 + i;
+        if (tap < 9) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                slab[((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31)] = acc[i][reg];
+            }
+        }
+    }
+    if (does_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) p.bias_slab[(size_t)blockIdx.x * NG + 32 * nt + lane] = bsum;
+    }
+}
+
+// dw_x[tap][c][gate*F+ch] (+)= sum_blocks slab[blk][tap][c][ch*4+gate], same for dw_h and dbias.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nblk,
+                                    int MT, int C, int Cs, int accumulate, float* __restrict__ dw_x,
+                                    float* __restrict__ dw_h, float* __restrict__ dbias) {
+    const int n_x = 9 * C * NG, n_h = 9 * F_ * NG;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_x + n_h + NG) return;
+    const size_t per_blk = (size_t)9 * (MT * 32) * NG;
+    float sum = 0.0f;
+    float* dst;
+    if (idx < n_x + n_h) {
+        int tap, c, col;
+        if (idx < n_x) {
+            tap = idx / (C * NG);
+            const int rem = idx - tap * C * NG;
+            c = rem / NG;
+            col = rem - c * NG;
+            dst = dw_x + idx;
+        } else {
+            const int j = idx - n_x;
+            tap = j / (F_ * NG);
+            const int rem = j - tap * F_ * NG;
+            c = Cs + rem / NG;
+            col = rem % NG;
+            dst = dw_h + j;
+        }
+        const int gate = col / F_, ch = col - gate * F_;
+        const size_t off = ((size_t)tap * (MT * 32) + c) * NG + ch * 4 + gate;
+        for (int b = 0; b < nblk; ++b) sum += slab[b * per_blk + off];
+    } else {
+        const int col = idx - n_x - n_h;
+        const int gate = col / F_, ch = col - gate * F_;
+        for (int b = 0; b < nblk; ++b) sum += bias_slab[(size_t)b * NG + ch * 4 + gate];
+        dst = dbias + col;
+    }
+    if (dst) *dst = accumulate ? *dst + sum : sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+    ISG_REQUIRE(lds <= 160 * 1024, ISG_EINVAL, "LDS request %zu exceeds 160 KiB", lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    return ISG_OK;
+}
+
+int check_channels(const char* who, int Cs, int dtype) {
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "%s: dtype %d", who, dtype);
+    const int mult = dtype == ISG_BF16 ? 16 : 4;
+    ISG_REQUIRE(Cs >= mult && Cs % mult == 0 && Cs <= 112, ISG_EINVAL,
+                "%s: input channel stride %d must be a multiple of %d (pad with zero channels) and <= 112", who, Cs,
+                mult);
+    return ISG_OK;
+}
+
+template <typename T>
+size_t conv_lds_bytes(int cpt, int spt, int MT, bool with_bias) {
+    const size_t w = Tr<T>::W_IN_LDS ? (size_t)9 * spt * MT * 64 * sizeof(typename Tr<T>::frag) : 0;
+    const size_t in = ((size_t)NPX * (cpt * sizeof(T) + Tr<T>::PAD) + 15) & ~(size_t)15;
+    return w + in + (with_bias ? NG * sizeof(float) : 0);
+}
+
+template <typename T, int MT, int MODE>
+int launch_conv(ConvParams& p, hipStream_t stream) {
+    const int cpt = p.c0 + p.c1;
+    const size_t lds = conv_lds_bytes<T>(cpt, p.spt, MT, MODE == 0);
+    int rc = set_lds(&conv3x3_kernel<T, MT, MODE>, lds);
+    if (rc != ISG_OK) return rc;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int grid = ntiles < num_cus() * per_cu ? ntiles : num_cus() * per_cu;
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, MODE>), dim3(grid), dim3(kThreads), lds, stream, p);
+    return isg::check_launch("conv3x3_kernel");
+}
+
+}  // namespace
+
+extern "C" long long isg_convlstm_packed_elems(int Cs, int F, int kind) {
+    if (F != F_ || Cs <= 0) return -1;
+    if (kind == 0) return (long long)9 * (Cs + F_) * NG;  // forward image: 64 rows x K
+    const int MT = (Cs + F_ + 31) / 32;
+    return (long long)9 * NG * MT * 32;  // dgrad image: MT*32 rows x (9 * 64)
+}
+
+extern "C" int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int F, int dtype,
+                                         void* packed_fwd, void* packed_dgrad, void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(w_x && w_h && C >= 1 && C <= Cs, ISG_EINVAL, "isg_convlstm_pack_weights: bad arguments");
+    int rc = check_channels("isg_convlstm_pack_weights", Cs, dtype);
+    if (rc != ISG_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int MT = (Cs + F_ + 31) / 32;
+    ISG_REQUIRE(MT <= 4, ISG_EINVAL, "isg_convlstm: too many input channels");
+    for (int kind = 0; kind < 2; ++kind) {
+        void* out = kind == 0 ? packed_fwd : packed_dgrad;
+        if (!out) continue;
+        const long long total = isg_convlstm_packed_elems(Cs, F, kind);
+        const int mt = kind == 0 ? 2 : MT;
+        const int blocks = (int)((total + 255) / 256);
+        if (dtype == ISG_F32)
+            hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, Cs, kind, mt,
+                               static_cast<float*>(out), total);
+        else
+            hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, Cs, kind, mt,
+                               static_cast<__bf16*>(out), total);
+        rc = isg::check_launch("pack_weights_kernel");
+        if (rc != ISG_OK) return rc;
+    }
+    return ISG_OK;
+}
+
+extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+                                     const float* bias, int B, int H, int W, int Cs, int F, int dtype,
+                                     const int32_t* durations, int t, void* h_out, float* c_out, void* out,
+                                     long long out_batch_stride, void* gates, void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(x && h_prev && c_prev && packed_fwd && bias && h_out && c_out, ISG_EINVAL,
+                "isg_convlstm_cell_fwd: null pointer");
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_cell_fwd: bad shape");
+    int rc = check_channels("isg_convlstm_cell_fwd", Cs, dtype);
+    if (rc != ISG_OK) return rc;
+    ConvParams p = {};
+    p.in0 = x, p.in1 = h_prev, p.c0 = Cs, p.c1 = F_;
+    p.B = B, p.H = H, p.W = W;
+    p.wimg = packed_fwd;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.durations = durations, p.t = t;
+    p.bias = bias, p.c_prev = c_prev, p.c_out = c_out, p.h_out = h_out, p.out = out;
+    p.out_bstride = out_batch_stride, p.gates = gates;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32) {
+        p.spt = (Cs + F_) / 2;
+        return launch_conv<float, 2, 0>(p, s);
+    }
+    p.spt = (Cs + F_) / 16;
+    return launch_conv<__bf16, 2, 0>(p, s);
+}
+
+extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur,
+                                          const void* dh_above, long long dh_above_batch_stride,
+                                          const void* dh_state, const float* dc_state, int B, int H, int W, int F,
+                                          int dtype, const int32_t* durations, int t, void* dy, float* dc_prev,
+                                          void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(gates && c_prev && c_cur && dy && dc_prev, ISG_EINVAL, "isg_convlstm_pointwise_bwd: null pointer");
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_convlstm_pointwise_bwd: dtype %d", dtype);
+    PointwiseParams p = {};
+    p.gates = gates, p.c_prev = c_prev, p.c_cur = c_cur;
+    p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride;
+    p.dh_state = dh_state, p.dc_state = dc_state, p.dc_prev = dc_prev, p.dy = dy;
+    p.durations = durations, p.t = t, p.B = B, p.HW = H * W;
+    const long long total = (long long)B * H * W * (F_ / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, p);
+    return isg::check_launch("lstm_pointwise_bwd_kernel");
+}
+
+extern "C" int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int B, int H, int W, int Cs, int F,
+                                  int dtype, const int32_t* durations, int t, void* dx, int dx_channels,
+                                  int dx_channel_stride, int dx_accumulate, void* dh_prev, void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(dy && packed_dgrad && dh_prev, ISG_EINVAL, "isg_convlstm_dgrad: null pointer");
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_dgrad: bad shape");
+    int rc = check_channels("isg_convlstm_dgrad", Cs, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(!dx || (dx_channels >= 4 && dx_channels % 4 == 0 && dx_channels <= Cs &&
+                        dx_channel_stride % 4 == 0 && dx_channel_stride >= dx_channels),
+                ISG_EINVAL, "isg_convlstm_dgrad: dx channels/stride must be multiples of 4 within the input width");
+    ConvParams p = {};
+    p.in0 = dy, p.in1 = nullptr, p.c0 = NG, p.c1 = 0;
+    p.B = B, p.H = H, p.W = W;
+    p.wimg = packed_dgrad;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.durations = durations, p.t = t;
+    p.dx = dx, p.dx_channels = dx ? dx_channels : 0, p.dx_cstride = dx_channel_stride, p.dx_accumulate = dx_accumulate;
+    p.dh_prev = dh_prev;
+    p.row_split = Cs;
+    p.spt = dtype == ISG_F32 ? NG / 2 : NG / 16;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int MT = (Cs + F_ + 31) / 32;
+    if (dtype == ISG_F32) {
+        if (MT == 1) return launch_conv<float, 1, 1>(p, s);
+        if (MT == 2) return launch_conv<float, 2, 1>(p, s);
+        if (MT == 3) return launch_conv<float, 3, 1>(p, s);
+        return launch_conv<float, 4, 1>(p, s);
+    }
+    if (MT == 1) return launch_conv<__bf16, 1, 1>(p, s);
+    if (MT == 2) return launch_conv<__bf16, 2, 1>(p, s);
+    if (MT == 3) return launch_conv<__bf16, 3, 1>(p, s);
+    return launch_conv<__bf16, 4, 1>(p, s);
+}
+
+extern "C" long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F) {
+    if (F != F_ || Cs <= 0 || Cs + F_ > 64) return -1;
+    const int MT = (Cs + F_ + 31) / 32;
+    return (long long)kWgradMaxBlocks * ((long long)9 * MT * 32 * NG + NG) * (long long)sizeof(float);
+}
+
+extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C,
+                                  int Cs, int F, int dtype, const int32_t* durations, int t, void* workspace,
+                                  int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(x && h_prev && dy && workspace && dw_x && dw_h && dbias, ISG_EINVAL,
+                "isg_convlstm_wgrad: null pointer");
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= Cs, ISG_EINVAL, "isg_convlstm_wgrad: bad shape");
+    int rc = check_channels("isg_convlstm_wgrad", Cs, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(Cs + F_ <= 64, ISG_EINVAL, "isg_convlstm_wgrad: at most %d input channels (got %d)", 64 - F_, Cs);
+    const int MT = (Cs + F_ + 31) / 32;
+    WgradParams p = {};
+    p.in0 = x, p.in1 = h_prev, p.c0 = Cs, p.c1 = F_, p.dy = dy;
+    p.B = B, p.H = H, p.W = W;
+    p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
+    p.durations = durations, p.t = t;
+    const int ntiles = p.tiles_x * p.tiles_y * B;
+    const int grid = ntiles < kWgradMaxBlocks ? ntiles : kWgradMaxBlocks;
+    p.slab = static_cast<float*>(workspace);
+    p.bias_slab = p.slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t esz = dtype == ISG_F32 ? 4 : 2, pad = dtype == ISG_F32 ? 4 : 16;
+    const size_t lds = (((size_t)NPX * ((Cs + F_) * esz + pad) + 15) & ~(size_t)15) + (size_t)TH * TW * (NG * esz + pad);
+    if (dtype == ISG_F32) {
+        if (MT == 1) {
+            if ((rc = set_lds(&conv_wgrad_kernel<float, 1>, lds)) != ISG_OK) return rc;
+            hipLaunchKernelGGL((conv_wgrad_kernel<float, 1>), dim3(grid), dim3(kThreads), lds, s, p);
+        } else {
+            if ((rc = set_lds(&conv_wgrad_kernel<float, 2>, lds)) != ISG_OK) return rc;
+            hipLaunchKernelGGL((conv_wgrad_kernel<float, 2>), dim3(grid), dim3(kThreads), lds, s, p);
+        }
+    } else {
+        if (MT == 1) {
+            if ((rc = set_lds(&conv_wgrad_kernel<__bf16, 1>, lds)) != ISG_OK) return rc;
+            hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), dim3(grid), dim3(kThreads), lds, s, p);
+        } else {
+            if ((rc = set_lds(&conv_wgrad_kernel<__bf16, 2>, lds)) != ISG_OK) return rc;
+            hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 2>), dim3(grid), dim3(kThreads), lds, s, p);
+        }
+    }
+    if ((rc = isg::check_launch("conv_wgrad_kernel")) != ISG_OK) return rc;
+    const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, p.bias_slab, grid, MT,
+                       C, Cs, accumulate, dw_x, dw_h, dbias);
+    return isg::check_launch("wgrad_reduce_kernel");
+}

@@ -1,0 +1,133 @@
+"""Thin tensor-level wrappers over the ConvLSTM entry points of libisg (include/isg.h).
+
+Every function enqueues HIP kernels on torch's current stream and returns torch tensors; none has a
+CPU path.  Activations are NHWC, float32 or bfloat16; the cell state and parameter gradients are
+float32.
+"""
+import torch
+
+from . import _lib
+
+F_HIDDEN = 16  # the kernels are specialised for the reference's 16 hidden channels
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.bfloat16:
+        return 1
+    raise TypeError("libisg stores activations as float32 or bfloat16, not %s" % dtype)
+
+
+def channel_multiple(dtype):
+    return 16 if dtype == torch.bfloat16 else 4
+
+
+def padded_channels(c, dtype):
+    m = channel_multiple(dtype)
+    return (c + m - 1) // m * m
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: libisg has no CPU path" % name)
+
+
+class PackedWeights:
+    """MFMA operand images of one cell's weights (forward + data-gradient), see
+    isg_convlstm_pack_weights."""
+
+    def __init__(self, w_x, w_h, bias, cs, dtype):
+        _need_cuda(w_x, "w_x")
+        self.c = int(w_x.shape[2])
+        self.cs = int(cs)
+        self.f = int(w_h.shape[2])
+        self.dtype = dtype
+        lib = _lib.lib()
+        n_fwd = lib.isg_convlstm_packed_elems(self.cs, self.f, 0)
+        n_dg = lib.isg_convlstm_packed_elems(self.cs, self.f, 1)
+        if n_fwd < 0 or n_dg < 0:
+            raise _lib.IsgError("unsupported ConvLSTM shape: C=%d (stride %d), F=%d" % (self.c, self.cs, self.f))
+        self.fwd = torch.empty([n_fwd], dtype=dtype, device=w_x.device)
+        self.dgrad = torch.empty([n_dg], dtype=dtype, device=w_x.device)
+        self.bias = bias.detach().to(torch.float32).contiguous()
+        w_x32 = w_x.detach().to(torch.float32).contiguous()
+        w_h32 = w_h.detach().to(torch.float32).contiguous()
+        rc = lib.isg_convlstm_pack_weights(_lib.ptr(w_x32), _lib.ptr(w_h32), self.c, self.cs, self.f,
+                                           dtype_code(dtype), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
+                                           _lib.current_stream())
+        _lib.check(rc, "isg_convlstm_pack_weights")
+
+
+def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
+             h_out=None, c_out=None, gates=None):
+    """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
+    Returns (h, c, gates)."""
+    _need_cuda(x, "x")
+    B, H, W, Cs = x.shape
+    F = packed.f
+    assert Cs == packed.cs and x.dtype == packed.dtype and h_prev.dtype == packed.dtype
+    assert c_prev.dtype == torch.float32
+    h = torch.empty([B, H, W, F], dtype=x.dtype, device=x.device) if h_out is None else h_out
+    c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
+    if gates is None and save_gates:
+        gates = torch.empty([B, H, W, F, 4], dtype=x.dtype, device=x.device)
+    rc = _lib.lib().isg_convlstm_cell_fwd(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd),
+                                          _lib.ptr(packed.bias), B, H, W, Cs, F, dtype_code(x.dtype),
+                                          _lib.ptr(durations), int(t), _lib.ptr(h), _lib.ptr(c),
+                                          out.data_ptr() if out is not None else None, int(out_batch_stride),
+                                          _lib.ptr(gates), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_cell_fwd")
+    return h, c, gates
+
+
+def pointwise_bwd(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, durations=None, t=0,
+                  dy=None, dc_prev=None):
+    """Gate backward. Returns (dy [B,H,W,F,4], dc_prev float32 [B,H,W,F])."""
+    B, H, W, F, _ = gates.shape
+    dy = torch.empty_like(gates) if dy is None else dy
+    dc_prev = torch.empty([B, H, W, F], dtype=torch.float32, device=gates.device) if dc_prev is None else dc_prev
+    rc = _lib.lib().isg_convlstm_pointwise_bwd(
+        _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(c_cur), dh_above.data_ptr() if dh_above is not None else None,
+        int(dh_above_batch_stride), _lib.ptr(dh_state), _lib.ptr(dc_state), B, H, W, F, dtype_code(gates.dtype),
+        _lib.ptr(durations), int(t), _lib.ptr(dy), _lib.ptr(dc_prev), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_pointwise_bwd")
+    return dy, dc_prev
+
+
+def dgrad(dy, packed, dh_prev, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0):
+    """Data gradient. dh_prev [B,H,W,F] is written (left untouched for masked samples); dx optional."""
+    B, H, W, F, _ = dy.shape
+    rc = _lib.lib().isg_convlstm_dgrad(
+        _lib.ptr(dy), _lib.ptr(packed.dgrad), B, H, W, packed.cs, F, dtype_code(dy.dtype), _lib.ptr(durations),
+        int(t), _lib.ptr(dx), int(dx_channels), int(dx.shape[-1]) if dx is not None else 0, int(bool(dx_accumulate)),
+        _lib.ptr(dh_prev), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_dgrad")
+    return dx, dh_prev
+
+
+_workspaces = {}
+
+
+def wgrad_workspace(cs, f, device):
+    key = (cs, f, str(device))
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = _lib.lib().isg_convlstm_wgrad_workspace_bytes(cs, f)
+        if nbytes < 0:
+            raise _lib.IsgError("weight gradient supports at most %d input channels (got %d)" % (64 - f, cs))
+        ws = torch.empty([nbytes // 4], dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0):
+    """Parameter gradients of one step into float32 dw_x [3,3,C,4F], dw_h [3,3,F,4F], dbias [4F]."""
+    B, H, W, Cs = x.shape
+    F = h_prev.shape[-1]
+    ws = wgrad_workspace(Cs, F, x.device)
+    rc = _lib.lib().isg_convlstm_wgrad(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(dy), B, H, W, int(c_real), Cs, F,
+                                       dtype_code(x.dtype), _lib.ptr(durations), int(t), _lib.ptr(ws),
+                                       int(bool(accumulate)), _lib.ptr(dw_x), _lib.ptr(dw_h), _lib.ptr(dbias),
+                                       _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_wgrad")

@@ -78,6 +78,63 @@ int isg_shape_mask(const int32_t* verts, const int32_t* nverts, int n, int vmax,
 int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out, int out_channels,
                        int out_offset, void* stream);
 
+/* ---- ConvLSTM cell ------------------------------------------------------------------------
+ * One step of the reference cell (reference convLSTM.py:26-45):
+ *     y = conv(h_prev, W_h, SAME) + conv(x, W_x, SAME) + b ;  j, i, f, o = split(y, 4)
+ *     c = sigmoid(f) * c_prev + sigmoid(i) * tanh(j) ;  h = sigmoid(o) * tanh(c)
+ * as it runs inside tf.nn.dynamic_rnn(sequence_length=duration) (reference
+ * polyrnn/History2LargeExperiment.py:31-46): where durations != NULL and t >= durations[b], the
+ * state of sample b is copied through and its emitted output is zero.
+ *
+ * Storage: activations (x, h, gate buffers, their gradients) have `dtype` ISG_F32 or ISG_BF16,
+ * NHWC; the cell state c and all parameter gradients are always float.  F must be 16.
+ * x has Cs allocated channels per pixel, Cs % 16 == 0 (bf16) or Cs % 4 == 0 (f32); channels beyond
+ * the C real ones must hold finite values (they meet zero weights).
+ * Weights stay in the reference's layout, w_x float [3][3][C][4F], w_h float [3][3][F][4F], bias
+ * float [4F] (gate blocks j|i|f|o); isg_convlstm_pack_weights turns them into the MFMA operand
+ * images the kernels read (call it again whenever the weights change).
+ */
+
+/* Elements (of `dtype`) of a packed image: kind 0 = forward image, 1 = data-gradient image. */
+long long isg_convlstm_packed_elems(int Cs, int F, int kind);
+
+int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int F, int dtype,
+                              void* packed_fwd, void* packed_dgrad /* either may be NULL */, void* stream);
+
+/* Forward step.  h_out/c_out: new state [B][H][W][F].  out (optional): the emitted output, written
+ * at out + b*out_batch_stride + (y*W + x)*F so that it can land in a [B][T][H][W][F] tensor.
+ * gates (optional): [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), kept for the
+ * backward pass. */
+int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+                          const float* bias, int B, int H, int W, int Cs, int F, int dtype,
+                          const int32_t* durations, int t, void* h_out, float* c_out, void* out,
+                          long long out_batch_stride, void* gates, void* stream);
+
+/* Backward, step 1 (pointwise): from dL/dh (= dh_above as emitted output + dh_state as carried
+ * state, either may be NULL) and dL/dc (dc_state, may be NULL) to the pre-activation gradient
+ * dy [B][H][W][F][4] and dc_prev (may alias dc_state).  Replaces the gradient of
+ * reference convLSTM.py:40-43 that tf.gradients derives (reference polyrnn/Model.py:108). */
+int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
+                               long long dh_above_batch_stride, const void* dh_state, const float* dc_state, int B,
+                               int H, int W, int F, int dtype, const int32_t* durations, int t, void* dy,
+                               float* dc_prev, void* stream);
+
+/* Backward, step 2 (data gradient of reference convLSTM.py:36-37): dx (optional; first
+ * dx_channels channels, pixel stride dx_channel_stride, += when dx_accumulate) and dh_prev
+ * [B][H][W][F].  For a masked sample dh_prev is left as it is (it already holds the carried
+ * state gradient) and dx is zero. */
+int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int B, int H, int W, int Cs, int F, int dtype,
+                       const int32_t* durations, int t, void* dx, int dx_channels, int dx_channel_stride,
+                       int dx_accumulate, void* dh_prev, void* stream);
+
+/* Backward, step 3 (parameter gradients): dw_x [3][3][C][4F], dw_h [3][3][F][4F], dbias [4F], all
+ * float, overwritten or (accumulate != 0) added to.  workspace: device scratch of
+ * isg_convlstm_wgrad_workspace_bytes(Cs, F) bytes; needs Cs + F <= 64. */
+long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F);
+int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C, int Cs, int F,
+                       int dtype, const int32_t* durations, int t, void* workspace, int accumulate, float* dw_x,
+                       float* dw_h, float* dbias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

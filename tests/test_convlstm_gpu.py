@@ -1,0 +1,182 @@
+"""HIP ConvLSTM kernels against the float64 NumPy oracle (oracle/convlstm.py).
+
+Tolerances: float32 storage / f32 MFMA - 1e-4 relative to the tensor's largest magnitude (the
+reference-parity bar); bfloat16 storage / bf16 MFMA with float32 accumulation - 3e-2 of the tensor's
+largest magnitude (8 significant bits on inputs, weights and saved activations)."""
+import numpy as np
+import pytest
+
+from oracle import convlstm as oc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 3e-2}
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def close(got, ref, dtype, what, scale=None):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    denom = max(np.abs(ref).max() if scale is None else scale, 1e-6)
+    err = np.abs(got - ref).max() / denom
+    assert err <= TOL[dtype], "%s: max error %.3e of max |ref| (tolerance %.1e)" % (what, err, TOL[dtype])
+
+
+def rand_cell(rs, C, F=16, scale=0.3):
+    return (rs.randn(3, 3, C, 4 * F) * scale / np.sqrt(C), rs.randn(3, 3, F, 4 * F) * scale / 4, rs.randn(4 * F) * 0.2)
+
+
+def make_cell(C, w_x, w_h, bias, dtype, shape):
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell
+    cell = ConvLSTMCell(shape=list(shape), filters=16, kernel=[3, 3], compute_dtype=dtype, device=dev())
+    cell.build(C, dev())
+    with torch.no_grad():
+        cell.input_to_state_kernel.copy_(torch.tensor(w_x))
+        cell.hidden_to_state_kernel.copy_(torch.tensor(w_h))
+        cell.bias.copy_(torch.tensor(bias))
+    return cell
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 28, 28, 18), (1, 9, 37, 5), (3, 32, 32, 16), (1, 8, 64, 33), (2, 17, 5, 48)])
+def test_cell_forward(dtype, B, H, W, C):
+    rs = np.random.RandomState(B * 1000 + H * 10 + C)
+    x, c, h = rs.randn(B, H, W, C), rs.randn(B, H, W, 16), rs.randn(B, H, W, 16) * 0.5
+    w_x, w_h, bias = rand_cell(rs, C)
+    cell = make_cell(C, w_x, w_h, bias, dtype, (H, W))
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    with torch.no_grad():
+        out, (c2, h2) = cell(t(x, dtype), (t(c), t(h, dtype)))
+    if dtype == torch.bfloat16:  # the kernel sees bf16-rounded inputs and weights: give the oracle the same
+        r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+        x, h, w_x, w_h = r(x), r(h), r(w_x), r(w_h)
+    rh, rc = oc.cell_forward(x, c, h, w_x, w_h, bias)
+    assert out.dtype == dtype and c2.dtype == torch.float32 and out.data_ptr() == h2.data_ptr()
+    close(h2, rh, dtype, "h")
+    close(c2, rc, dtype, "c")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 28, 28, 18), (1, 9, 37, 5), (2, 32, 32, 16), (1, 12, 40, 33)])
+def test_cell_backward(dtype, B, H, W, C):
+    rs = np.random.RandomState(7 + B * 1000 + H * 10 + C)
+    x, c, h = rs.randn(B, H, W, C), rs.randn(B, H, W, 16), rs.randn(B, H, W, 16) * 0.5
+    w_x, w_h, bias = rand_cell(rs, C)
+    dh, dc = rs.randn(B, H, W, 16), rs.randn(B, H, W, 16)
+    cell = make_cell(C, w_x, w_h, bias, dtype, (H, W))
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    tx, tc, th = t(x, dtype).requires_grad_(True), t(c).requires_grad_(True), t(h, dtype).requires_grad_(True)
+    out, (c2, h2) = cell(tx, (tc, th))
+    (out.float() * t(dh)).sum().add((c2 * t(dc)).sum()).backward()
+    if dtype == torch.bfloat16:
+        r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+        x, h, w_x, w_h, dh = r(x), r(h), r(w_x), r(w_h), r(dh)
+    _, _, cache = oc.cell_forward(x, c, h, w_x, w_h, bias, return_cache=True)
+    g = oc.cell_backward(cache, w_x, w_h, dh, dc)
+    close(tx.grad, g["dx"], dtype, "dx")
+    close(th.grad, g["dh_prev"], dtype, "dh_prev")
+    close(tc.grad, g["dc_prev"], dtype, "dc_prev")
+    close(cell.input_to_state_kernel.grad, g["dw_x"], dtype, "dw_x")
+    close(cell.hidden_to_state_kernel.grad, g["dw_h"], dtype, "dw_h")
+    close(cell.bias.grad, g["dbias"], dtype, "dbias")
+
+
+def _stack(rs, C, layers, dtype, shape):
+    from imagesegmentation_amd.convLSTM import MultiRNNCell
+    params, cells, c = [], [], C
+    for _ in range(layers):
+        w_x, w_h, bias = rand_cell(rs, c)
+        params.append(dict(w_x=w_x, w_h=w_h, bias=bias))
+        cells.append(make_cell(c, w_x, w_h, bias, dtype, shape))
+        c = 16
+    return params, MultiRNNCell(cells)
+
+
+def _round_params(params):
+    r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+    return [dict(w_x=r(p["w_x"]), w_h=r(p["w_h"]), bias=p["bias"]) for p in params]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dynamic_rnn_forward_backward_with_sequence_lengths(dtype):
+    from imagesegmentation_amd.convLSTM import dynamic_rnn
+    rs = np.random.RandomState(11)
+    T, B, H, W, C, L = 4, 5, 28, 28, 18, 2
+    params, multi = _stack(rs, C, L, dtype, (H, W))
+    x = rs.randn(T, B, H, W, C)
+    durations = np.array([4, 0, 2, 1, 3], np.int32)
+    init = [(rs.randn(B, H, W, 16) * 0.3, rs.randn(B, H, W, 16) * 0.3) for _ in range(L)]
+    d_out = rs.randn(T, B, H, W, 16)
+    d_fin = [(rs.randn(B, H, W, 16), rs.randn(B, H, W, 16)) for _ in range(L)]
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    tx = t(x, dtype).requires_grad_(True)
+    tinit = tuple((t(c).requires_grad_(True), t(h, dtype).requires_grad_(True)) for c, h in init)
+    out, final = dynamic_rnn(multi, tx, sequence_length=durations, initial_state=tinit, time_major=True)
+    loss = (out.float() * t(d_out)).sum()
+    for l in range(L):
+        loss = loss + (final[l].c * t(d_fin[l][0])).sum() + (final[l].h.float() * t(d_fin[l][1])).sum()
+    loss.backward()
+    if dtype == torch.bfloat16:
+        r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+        x, params = r(x), _round_params(params)
+        init = [(c, r(h)) for c, h in init]
+    ro, rf, caches = oc.rnn_forward(x, durations, params, init, return_cache=True)
+    close(out, ro, dtype, "outputs")
+    assert float(out[:, 1].abs().max()) == 0.0 and float(out[2:, 2].abs().max()) == 0.0
+    for l in range(L):
+        close(final[l].c, rf[l][0], dtype, "final c[%d]" % l)
+        close(final[l].h, rf[l][1], dtype, "final h[%d]" % l)
+    d_in, grads, d_init = oc.rnn_backward(caches, durations, params, d_out, d_fin)
+    close(tx.grad, d_in, dtype, "d_inputs")
+    for l in range(L):
+        cell = multi.cells[l]
+        close(cell.input_to_state_kernel.grad, grads[l]["dw_x"], dtype, "dw_x[%d]" % l)
+        close(cell.hidden_to_state_kernel.grad, grads[l]["dw_h"], dtype, "dw_h[%d]" % l)
+        close(cell.bias.grad, grads[l]["dbias"], dtype, "dbias[%d]" % l)
+        close(tinit[l][0].grad, d_init[l][0], dtype, "d_init c[%d]" % l)
+        close(tinit[l][1].grad, d_init[l][1], dtype, "d_init h[%d]" % l)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dense", [True, False])
+def test_tiled_features_plus_history_input(dtype, dense):
+    """The reference's tile(conv3) ++ history input without materialising the tiled tensor."""
+    from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
+    rs = np.random.RandomState(13)
+    T, B, P, Cf, hist, L = 3, 3, 28, 16, 2, 2
+    params, multi = _stack(rs, Cf + hist, L, dtype, (P, P))
+    feat = rs.randn(B, P, P, Cf)
+    pts = rs.randint(0, P, [B, T, hist, 2]).astype(np.int32)
+    pts[0, 1, 0] = (-1, -1)  # an empty frame
+    histories = np.zeros([B, T, P, P, hist])
+    for b in range(B):
+        for t_ in range(T):
+            for i in range(hist):
+                if pts[b, t_, i, 0] >= 0:
+                    histories[b, t_, pts[b, t_, i, 1], pts[b, t_, i, 0], i] = 1
+    durations = np.array([3, 2, 1], np.int32)
+    d_out = rs.randn(T, B, P, P, 16)
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    tfeat = t(feat, dtype).requires_grad_(True)
+    seq = SequenceInput(static=tfeat, hist_dense=t(histories, dtype)) if dense else \
+        SequenceInput(static=tfeat, hist_points=torch.tensor(pts, device=dev()))
+    out, final = dynamic_rnn(multi, seq, sequence_length=durations, time_major=True)
+    (out.float() * t(d_out)).sum().backward()
+    if dtype == torch.bfloat16:
+        r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+        feat, params = r(feat), _round_params(params)
+    x = np.concatenate([np.broadcast_to(feat[None], (T,) + feat.shape), np.transpose(histories, (1, 0, 2, 3, 4))],
+                       axis=4)
+    ro, rf, caches = oc.rnn_forward(x, durations, params, None, return_cache=True)
+    close(out, ro, dtype, "outputs")
+    d_in, grads, _ = oc.rnn_backward(caches, durations, params, d_out)
+    close(tfeat.grad, d_in[..., :Cf].sum(axis=0), dtype, "d_features")
+    for l in range(L):
+        close(multi.cells[l].input_to_state_kernel.grad, grads[l]["dw_x"], dtype, "dw_x[%d]" % l)
+        close(multi.cells[l].bias.grad, grads[l]["dbias"], dtype, "dbias[%d]" % l)
