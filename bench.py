@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Benchmark of the two hot paths on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline (the JSON line's metric/value): polygon sequences per second, forward + backward + optimiser,
+of the RNNConvExperiment graph (encoder 32@14,32@5,32@3 -> 2 x ConvLSTM(16) -> head) on 224 x 224
+synthetic polygons, batch 64 per GPU, teacher forced, T = 5 - BASELINE.json configs[1].  The
+reference's dense head (P*P*16 -> P*P) has 4e10 weights at P = 224 and cannot exist; as the reference
+never runs above 28 x 28, the head here average-pools the recurrent output 8x to the 28 x 28 grid the
+reference's head was built for (Model(head_size=28)).
+
+Also reported in the same line: IoU rollouts per second of the rasteriser (16,384 rollouts at 224 x 224,
+masks materialised), per-kernel rooflines measured with events on the launch stream, and CPU baselines
+timed on the host cores in the same run (rank 0, N = 1 only).
+
+One process per GPU; for N > 1 launch through torch.distributed.run (RCCL all-reduce of the flat
+gradient bucket per step; the rasteriser shards rollouts with no collective).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--rollouts", type=int, default=16384, help="IoU rollouts per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(size, batch, T, hist, head_size, seed, device, dtype):
+    """Synthetic polygons by the reference generator recipe, rasterised by the HIP rasteriser, laid out
+    as the reference's teacher-forcing batch (history as vertex points, targets on the head grid)."""
+    from imagesegmentation_amd import data, util
+    cache = {}
+
+    def mask_fn(verts, s):
+        key = verts.tobytes()
+        if key not in cache:
+            cache.clear()
+            cache[key] = util.create_shape_mask(verts, s)
+        return cache[key]
+
+    ds = data.PolygonDataset.synthetic(batch, size, size, T, hist, seed=seed, shape_mask_fn=mask_fn)
+    np.random.seed(seed + 1)
+    d, images, pts, targets, verts = ds.get_batch_points(batch)
+    d = np.minimum(d, T).astype(np.int32)
+    scale = size // head_size
+    targets = targets // scale
+    return dict(durations=d, images=torch.as_tensor(images, device=device).to(dtype).contiguous(),
+                points=torch.as_tensor(pts, device=device), targets=torch.as_tensor(targets, device=device),
+                vertices=verts, images_np=images, points_np=pts, targets_np=targets)
+
+
+def event_time_ms(fn, reps):
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / reps
+
+
+def time_kernels(model, batch, dtype_name):
+    """Average launch duration of each ConvLSTM kernel at the workload's two layer shapes, with HIP events
+    on the stream the kernels are launched on (torch's current stream)."""
+    from imagesegmentation_amd import ops
+    dt = model.compute_dtype
+    dev = model.device
+    B, P = batch["images"].shape[0], model.prediction_size
+    F = 16
+    out = []
+    for l, cell in enumerate(model.rnn.cells):
+        packed = cell.packed()
+        cs, c_real = packed.cs, cell.input_to_state_kernel.shape[2]
+        x = torch.randn([B, P, P, cs], device=dev).to(dt)
+        h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
+        c = torch.randn([B, P, P, F], device=dev)
+        h2, c2 = torch.empty_like(h), torch.empty_like(c)
+        gates = torch.empty([B, P, P, F, 4], dtype=dt, device=dev)
+        dy = torch.empty_like(gates)
+        dh = torch.randn([B, P, P, F], device=dev).to(dt)
+        dc = torch.randn([B, P, P, F], device=dev)
+        dcp = torch.empty_like(dc)
+        dx = torch.empty([B, P, P, cs], dtype=dt, device=dev)
+        dhp = torch.empty_like(h)
+        dwx = torch.zeros_like(cell.input_to_state_kernel)
+        dwh = torch.zeros_like(cell.hidden_to_state_kernel)
+        db = torch.zeros_like(cell.bias)
+        flops = 2.0 * B * P * P * 9 * (c_real + F) * 4 * F
+        esz = 2 if dt == torch.bfloat16 else 4
+        px = B * P * P
+        kernels = [
+            ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates), flops, "mfma"),
+            ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
+             px * (2 * 4 * F * esz + 2 * F * esz + 4 * F * 4), "hbm"),
+            ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, "mfma"),
+            ("wgrad", lambda: ops.wgrad(x, h, dy, c_real, dwx, dwh, db, accumulate=False), flops, "mfma"),
+        ]
+        for name, fn, work, bound in kernels:
+            ms = event_time_ms(fn, 5)
+            rec = {"kernel": "%s[layer%d C=%d]" % (name, l, c_real), "ms": ms, "bound": bound}
+            if bound == "mfma":
+                rec.update(achieved=work / ms / 1e9, peak=MFMA_PEAK_TFLOPS[dtype_name], unit="TFLOP/s")
+            else:
+                rec.update(achieved=work / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
+            rec["frac"] = rec["achieved"] / rec["peak"]
+            out.append(rec)
+    return out
+
+
+def cpu_baseline_convlstm(model, batch, size, T, hist, head_size, budget_s=20.0):
+    """The same graph as stock torch CPU ops (oracle/torch_port.py) on the host cores, fp32, on a bounded
+    sample of the workload (2 sequences per pass)."""
+    from oracle import torch_port
+    threads = torch.get_num_threads()
+    n = 2
+    tp = {"encoder": [dict(w=w.detach().cpu().float().requires_grad_(True), b=b.detach().cpu().float().requires_grad_(True))
+                      for w, b in model.encoder],
+          "rnn": [dict(w_x=c.input_to_state_kernel.detach().cpu().float().requires_grad_(True),
+                       w_h=c.hidden_to_state_kernel.detach().cpu().float().requires_grad_(True),
+                       bias=c.bias.detach().cpu().float().requires_grad_(True)) for c in model.rnn.cells],
+          "dense": dict(w=model.dense_kernel.detach().cpu().float().requires_grad_(True),
+                        b=model.dense_bias.detach().cpu().float().requires_grad_(True))}
+    images = torch.as_tensor(batch["images_np"][:n]).float()
+    pts = batch["points_np"][:n]
+    hd = torch.zeros([n, T, size, size, hist])
+    for b in range(n):
+        for t in range(T):
+            for i in range(hist):
+                x, y = pts[b, t, i]
+                if x >= 0:
+                    hd[b, t, y, x, i] = 1
+    dur = torch.as_tensor(batch["durations"][:n].astype(np.int64))
+    labels = torch.as_tensor(batch["targets_np"][:n].astype(np.int64))
+    labels = labels[..., 0] * head_size + labels[..., 1]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        logits, _ = torch_port.model_logits(tp, images, hd, dur, head_pool=size // head_size)
+        loss = torch.nn.functional.cross_entropy(logits.reshape(n * T, -1), labels.reshape(-1))
+        loss.backward()
+        done += n
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 16:
+            break
+    return {"value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": "%d sequences (batch %d per pass) of the same 224x224 RNNConv workload, fwd+bwd, fp32 torch CPU "
+                      "ops, %.1f s" % (done, n, el)}
+
+
+def rollout_polygons(n, size, seed):
+    """Predicted (3..13 random vertices, as an untrained policy emits) and true (convex-ish) polygons."""
+    rs = np.random.RandomState(seed)
+    vmax = 16
+    nvp = rs.randint(3, 14, [n]).astype(np.int32)
+    vp = rs.randint(0, size, [n, vmax, 2]).astype(np.int32)
+    nvt = rs.randint(3, 9, [n]).astype(np.int32)
+    ang = np.sort(rs.uniform(0, 2 * np.pi, [n, vmax]), axis=1)
+    rad = rs.uniform(0.2, 0.48, [n, 1]) * size
+    ctr = size / 2.0
+    vt = np.stack([ctr + rad * np.cos(ang), ctr + rad * np.sin(ang)], axis=2).astype(np.int32)
+    return vp, nvp, vt, nvt
+
+
+def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
+    from imagesegmentation_amd import util
+    vp, nvp, vt, nvt = rollout_polygons(n, size, 100 + rank)
+    t = lambda a: torch.from_numpy(a).to(device)
+    VP, NVP, VT, NVT = t(vp), t(nvp), t(vt), t(nvt)
+    fn = lambda: util.raster_iou(VP, NVP, VT, NVT, size, want_masks=True)
+    for _ in range(max(warmup, 1)):
+        fn()
+    ms = event_time_ms(fn, steps)
+    fn_counts = lambda: util.raster_iou(VP, NVP, VT, NVT, size)
+    ms_counts = event_time_ms(fn_counts, steps)
+    bytes_per = 2 * size * size + 2 * vp.shape[1] * 8 + 8 + 8
+    res = {"rollouts_per_s": n / ms * 1e3, "ms_per_launch": ms, "rollouts": n, "size": size,
+           "counts_only_rollouts_per_s": n / ms_counts * 1e3,
+           "roofline": {"bound": "hbm", "achieved": n * bytes_per / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": n * bytes_per / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "raster_iou_kernel (masks materialised)"}}
+    if do_cpu:
+        import oracle
+        lib = oracle.load_c()
+        threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        sample = 512
+        i32p, u8p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8)
+        inter, union = np.zeros([sample], np.int32), np.zeros([sample], np.int32)
+        mp, mt = np.zeros([sample, size, size], np.uint8), np.zeros([sample, size, size], np.uint8)
+        args = [np.ascontiguousarray(a[:sample]) for a in (vp, nvp, vt, nvt)]
+        done, t0 = 0, time.perf_counter()
+        while True:
+            lib.isg_oracle_raster_iou(args[0].ctypes.data_as(i32p), args[1].ctypes.data_as(i32p),
+                                      args[2].ctypes.data_as(i32p), args[3].ctypes.data_as(i32p), sample,
+                                      vp.shape[1], size, inter.ctypes.data_as(i32p), union.ctypes.data_as(i32p),
+                                      mp.ctypes.data_as(u8p), mt.ctypes.data_as(u8p), threads)
+            done += sample
+            el = time.perf_counter() - t0
+            if el > 10.0:
+                break
+        gi, gu = fn_counts()
+        ok = bool(np.array_equal(gi[:sample].cpu().numpy(), inter) and np.array_equal(gu[:sample].cpu().numpy(), union))
+        res["cpu_baseline"] = {"value": done / el, "unit": "rollouts/s", "cores": threads, "kind": "port",
+                               "sample": "%d rollouts (the first %d of the launch, repeated) through the C oracle with "
+                                         "OpenMP, %.1f s; counts equal to the GPU's: %s" % (done, sample, el, ok)}
+    return res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    from imagesegmentation_amd.polyrnn import experiments
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    size, head_size = args.size, 28 if args.size % 28 == 0 else args.size
+    model = experiments.make("RNNConv", image_size=size, compute_dtype=dtype, device=device, seed=0,
+                             head_size=head_size)
+    T, hist = model.max_timesteps, model.history_length
+    batch = make_batch(size, args.batch, T, hist, head_size, seed=rank, device=device, dtype=dtype)
+
+    def step():
+        return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    seqs = args.batch * world * args.steps
+
+    # ---- rasteriser / IoU leg (sharded rollouts, no collective) ------------------------------
+    raster = bench_raster(args.rollouts, size, max(args.steps, 5), args.warmup, device, rank,
+                          do_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    if world > 1:
+        r = torch.tensor([raster["ms_per_launch"]], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.MAX)
+        raster["ms_per_launch"] = float(r.item())
+        raster["rollouts_per_s"] = args.rollouts * world / raster["ms_per_launch"] * 1e3
+        raster["rollouts"] = args.rollouts * world
+
+    kernels, roofline, cpu = None, None, None
+    if rank == 0 and not args.no_kernel_timing:
+        kernels = time_kernels(model, batch, args.dtype)
+        mf = [k for k in kernels if k["bound"] == "mfma"]
+        dom = max(mf, key=lambda k: k["ms"])
+        roofline = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
+                    "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "ms_per_launch": dom["ms"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_convlstm(model, batch, size, T, hist, head_size)
+
+    if rank == 0:
+        flop_seq = 3.0 * sum(2.0 * size * size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
+                             for c in model.rnn.cells) * float(np.mean(batch["durations"]))
+        line = {
+            "metric": "polygon seqs/sec fwd+bwd (ConvLSTM, 224²) & IoU rollouts/sec",
+            "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "polyrnn RNNConvExperiment graph, teacher-forced training step "
+                                   "(fwd+bwd+clip+Adam), %dx%d synthetic polygons, batch %d per GPU, T=%d, "
+                                   "2xConvLSTM(16), dense head on the 8x-pooled %dx%d grid" %
+                                   (size, size, args.batch, T, head_size, head_size),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "mean_duration": float(np.mean(batch["durations"]))},
+            "convlstm_mfma_frac_of_step": flop_seq * args.batch * world / (elapsed / args.steps) / 1e12 /
+            (MFMA_PEAK_TFLOPS[args.dtype] * world),
+            "loss": float(loss),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "iou": raster,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,10 @@ SIGNATURES = {
     "isg_raster_iou": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "isg_shape_mask": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_history_frames": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _int, _vp]),
+    "isg_softmax_xent_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "isg_softmax_xent_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp]),
+    "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
     "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp,
@@ -48,6 +52,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "libisg.so not found at %s - build it first: python -m imagesegmentation_amd.build" % LIB_PATH)
+        # torch first: libisg.so needs libamdhip64.so.7 and must share the HIP runtime instance that
+        # torch has loaded (same device context, same streams), not bring a second one in
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)

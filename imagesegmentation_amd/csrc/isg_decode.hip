@@ -1,0 +1,212 @@
+// Vertex decoding over the P*P (+1) class grid: softmax cross-entropy (forward / backward), argmax
+// with first-maximum tie-break, and categorical sampling.  One 64-lane wave owns one row; the row
+// (<= a few KB) is streamed once with a running (max, sum) pair and reduced across the wave with
+// shuffles - no LDS, no second pass over HBM.
+#include <hip/hip_bf16.h>
+
+#include "isg_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, long long i) {
+    return (float)p[i];
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// (value, index) maximum with the smaller index winning ties: tf.argmax's first-maximum rule
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(idx, o);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void xent_fwd_kernel(const T* __restrict__ logits,
+                                                                      const int* __restrict__ labels,
+                                                                      const float* __restrict__ weights, int rows,
+                                                                      int cols, float* __restrict__ loss_rows,
+                                                                      float* __restrict__ lse_rows,
+                                                                      int* __restrict__ argmax_rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    float m = -INFINITY, s = 0.0f;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = ld(z, c);
+        if (v > bv) {  // strictly greater: within a lane columns come in increasing order
+            bv = v;
+            bi = c;
+        }
+        if (v > m) {
+            s = s * expf(m - v) + 1.0f;
+            m = v;
+        } else {
+            s += expf(v - m);
+        }
+    }
+    const float gm = wave_max(m);
+    s = m == -INFINITY ? 0.0f : s * expf(m - gm);
+    s = wave_sum(s);
+    wave_argmax(bv, bi);
+    if (lane == 0) {
+        const float lse = gm + logf(s);
+        if (lse_rows) lse_rows[row] = lse;
+        if (argmax_rows) argmax_rows[row] = bi;
+        if (loss_rows) {
+            const int y = labels[row];
+            float l = (y >= 0 && y < cols) ? lse - ld(z, y) : NAN;  // TF yields NaN for a bad label
+            if (weights) l *= weights[row];
+            loss_rows[row] = l;
+        }
+    }
+}
+
+// dlogits[r][c] = (softmax[r][c] - [c == label]) * row_scale[r]
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void xent_bwd_kernel(const T* __restrict__ logits,
+                                                                      const int* __restrict__ labels,
+                                                                      const float* __restrict__ lse_rows,
+                                                                      const float* __restrict__ row_scale,
+                                                                      float uniform_scale, int rows, int cols,
+                                                                      T* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    T* d = dlogits + (size_t)row * cols;
+    const float lse = lse_rows[row];
+    const float sc = (row_scale ? row_scale[row] : 1.0f) * uniform_scale;
+    const int y = labels[row];
+    for (int c = lane; c < cols; c += 64) {
+        const float p = expf(ld(z, c) - lse);
+        d[c] = (T)((p - (c == y ? 1.0f : 0.0f)) * sc);
+    }
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// Gumbel-max categorical sample of softmax(logits[row]): argmax_c (z_c - log(-log u_c)),
+// u_c from a counter hash of (seed, global row, column).
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sample_kernel(const T* __restrict__ logits, int rows, int cols,
+                                                                    unsigned long long seed,
+                                                                    unsigned long long row_offset,
+                                                                    int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    const unsigned long long grow = row_offset + (unsigned long long)row;
+    const uint32_t key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9U)) ^
+                         mix32((uint32_t)grow * 0x85ebca6bU + (uint32_t)(grow >> 32));
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const uint32_t r = mix32(key + (uint32_t)c * 0xc2b2ae35U);
+        const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+        const float v = ld(z, c) - logf(-logf(u));
+        if (v > bv) {
+            bv = v;
+            bi = c;
+        }
+    }
+    wave_argmax(bv, bi);
+    if (lane == 0) out_idx[row] = bi;
+}
+
+int check_rows(const char* who, int rows, int cols, int dtype) {
+    ISG_REQUIRE(rows >= 0 && cols >= 1, ISG_EINVAL, "%s: bad shape rows=%d cols=%d", who, rows, cols);
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "%s: dtype %d", who, dtype);
+    return ISG_OK;
+}
+
+}  // namespace
+
+extern "C" int isg_softmax_xent_fwd(const void* logits, const int32_t* labels, const float* weights, int rows,
+                                    int cols, int dtype, float* loss_rows, float* lse_rows, int32_t* argmax_rows,
+                                    void* stream) {
+    int rc = check_rows("isg_softmax_xent_fwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && (labels || !loss_rows), ISG_EINVAL, "isg_softmax_xent_fwd: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(xent_fwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), labels,
+                           weights, rows, cols, loss_rows, lse_rows, argmax_rows);
+    else
+        hipLaunchKernelGGL(xent_fwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), labels, weights, rows, cols, loss_rows,
+                           lse_rows, argmax_rows);
+    return isg::check_launch("xent_fwd_kernel");
+}
+
+extern "C" int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, const float* lse_rows,
+                                    const float* row_scale, float scale, int rows, int cols, int dtype, void* dlogits,
+                                    void* stream) {
+    int rc = check_rows("isg_softmax_xent_bwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && labels && lse_rows && dlogits, ISG_EINVAL, "isg_softmax_xent_bwd: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(xent_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), labels,
+                           lse_rows, row_scale, scale, rows, cols, static_cast<float*>(dlogits));
+    else
+        hipLaunchKernelGGL(xent_bwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), labels, lse_rows, row_scale, scale, rows, cols,
+                           static_cast<__hip_bfloat16*>(dlogits));
+    return isg::check_launch("xent_bwd_kernel");
+}
+
+extern "C" int isg_argmax_rows(const void* logits, int rows, int cols, int dtype, int32_t* out_idx, void* stream) {
+    ISG_REQUIRE(out_idx || rows == 0, ISG_EINVAL, "isg_argmax_rows: null output");
+    return isg_softmax_xent_fwd(logits, nullptr, nullptr, rows, cols, dtype, nullptr, nullptr, out_idx, stream);
+}
+
+extern "C" int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                               unsigned long long row_offset, int32_t* out_idx, void* stream) {
+    int rc = check_rows("isg_sample_rows", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && out_idx, ISG_EINVAL, "isg_sample_rows: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(sample_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), rows, cols,
+                           seed, row_offset, out_idx);
+    else
+        hipLaunchKernelGGL(sample_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), rows, cols, seed, row_offset, out_idx);
+    return isg::check_launch("sample_kernel");
+}

@@ -1,0 +1,404 @@
+"""``Model``: the reference's estimator base (reference polyrnn/Model.py:16-274) on MI355X.
+
+Same constructor and method surface - ``Model(sess, max_timesteps, image_size, prediction_size,
+history_length, filepath)``, ``train / validate / validate_iou / save / maybe_restore`` - and the same
+graph semantics: CNN encoder -> tile over time -> concat history -> MultiRNNCell(ConvLSTM) under
+dynamic_rnn -> dense logits over the P x P (+1) grid; x-major class index; argmax decode; accuracy and
+L2 errors masked by duration; loss = mean cross-entropy over ALL B*T rows (padded steps included);
+clip_by_global_norm(1.0) + Adam(1e-4) in TensorFlow's form.
+
+There is no session or placeholder: ``sess`` is accepted and ignored, arrays are passed to the
+methods directly, and the tensors the reference exposes as graph nodes (``prediction_logits``,
+``prediction_max``, ``loss``, ``rnn_final_state`` ...) hold the values of the last evaluation.
+Subclasses describe their graph in ``_build_graph`` through ``self.encoder_spec``, ``self.rnn_layers``
+and ``self.end_token`` (see polyrnn/experiments.py).
+
+The recurrence runs in the HIP kernels of libisg (convLSTM.dynamic_rnn); the encoder convolutions and
+the dense head are plain torch ops (MIOpen / hipBLASLt).
+"""
+import json
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import util
+from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, SequenceInput, _run_sequence_forward, dynamic_rnn
+from . import decode
+
+
+def _glorot(shape, device, gen):
+    if len(shape) == 4:
+        fan_in, fan_out = shape[0] * shape[1] * shape[2], shape[0] * shape[1] * shape[3]
+    else:
+        fan_in, fan_out = shape
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, device=device, generator=gen) * 2 - 1) * limit
+
+
+def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
+    """tf.layers.conv2d(padding='same', activation=relu) on an NHWC tensor with an HWIO kernel
+    (reference polyrnn/History2LargeExperiment.py:15-22).  Even kernels pad (k-1)//2 before and the
+    rest after, as TensorFlow's SAME does."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    x = x_nhwc.permute(0, 3, 1, 2)  # NCHW view of channels-last memory
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    if kh % 2 == 0 or kw % 2 == 0:
+        x = F.pad(x, (pl, kw - 1 - pl, pt, kh - 1 - pt))
+        pad = 0
+    else:
+        pad = (pt, pl)
+    w = w_hwio.to(dtype).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+    y = F.relu(F.conv2d(x, w, b.to(dtype), padding=pad))
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+class Model:
+    #: overridden per experiment (reference: each *Experiment.py's ExperimentModel._build_graph)
+    encoder_spec = ((16, 5), (16, 5), (16, 3))
+    rnn_layers = 2
+    rnn_filters = 16
+    end_token = False
+
+    def __init__(self, sess, max_timesteps, image_size, prediction_size, history_length, filepath,
+                 compute_dtype=torch.float32, device=None, seed=0, head_size=None, learning_rate=1e-4,
+                 process_group=None):
+        self.sess = sess  # accepted for drop-in compatibility; there is no session
+        self.max_timesteps = max_timesteps
+        self.image_size = image_size
+        self.prediction_size = prediction_size
+        self.history_length = history_length
+        self._filepath = filepath
+        if image_size != prediction_size:
+            # the reference concatenates image features and history frames on the channel axis, which
+            # needs equal grids (polyrnn/History2LargeExperiment.py:25)
+            raise ValueError("image_size and prediction_size must match, as the reference's concat requires")
+        self.device = torch.device(device) if device is not None else util._device()
+        self.compute_dtype = compute_dtype
+        #: side of the grid the dense head predicts on; the reference always uses prediction_size.
+        #: A smaller value average-pools the recurrent output first (needed beyond ~64: the
+        #: reference's dense(P*P*16 -> P*P) has 4e10 weights at P = 224).
+        self.head_size = prediction_size if head_size is None else head_size
+        if prediction_size % self.head_size != 0:
+            raise ValueError("head_size must divide prediction_size")
+        self.learning_rate = learning_rate
+        self.process_group = process_group
+        self.global_step = 0
+        self.scope_name = 'Estimator'
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self._named = {}
+        self._build_graph()
+        self._make_variables()
+        self.trainable_variables = [p for _, p in self._named_parameters()]
+        self._adam_m = [torch.zeros_like(p) for p in self.trainable_variables]
+        self._adam_v = [torch.zeros_like(p) for p in self.trainable_variables]
+        n = sum(p.numel() for p in self.trainable_variables)
+        self._flat_grad = torch.zeros([n], dtype=torch.float32, device=self.device)
+        off = 0
+        for p in self.trainable_variables:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._events = None
+        # values of the last evaluation (graph nodes in the reference)
+        self.prediction_logits = None
+        self.loss = None
+        self.rnn_final_state = None
+        self.rnn_initial_state_pl = None
+        self.last_metrics = {}
+
+    # -- graph description ---------------------------------------------------------------------
+    def _build_graph(self):
+        """Subclasses set encoder_spec / rnn_layers / end_token here (or as class attributes)."""
+
+    @property
+    def num_classes(self):
+        return self.head_size ** 2 + (1 if self.end_token else 0)
+
+    def _make_variables(self):
+        dev, gen = self.device, self._gen
+        self.encoder = []
+        cin = 3
+        for n, (filters, k) in enumerate(self.encoder_spec):
+            w = torch.nn.Parameter(_glorot((k, k, cin, filters), dev, gen))
+            b = torch.nn.Parameter(torch.zeros([filters], device=dev))
+            self.encoder.append((w, b))
+            cin = filters
+        P = self.prediction_size
+        cells = []
+        for _ in range(self.rnn_layers):
+            cells.append(ConvLSTMCell(shape=[P, P], filters=self.rnn_filters, kernel=[3, 3],
+                                      initializer=lambda t: t.copy_(_glorot(tuple(t.shape), dev, gen)),
+                                      compute_dtype=self.compute_dtype, device=dev))
+        self.rnn = MultiRNNCell(cells)
+        self.rnn.build(cin + self.history_length, dev)
+        self.feature_channels = cin
+        hs = self.head_size
+        self.dense_kernel = torch.nn.Parameter(_glorot((hs * hs * self.rnn_filters, self.num_classes), dev, gen))
+        self.dense_bias = torch.nn.Parameter(torch.zeros([self.num_classes], device=dev))
+
+    def _named_parameters(self):
+        """(TensorFlow-style variable name, parameter) pairs, in creation order."""
+        s = self.scope_name
+        out = []
+        for n, (w, b) in enumerate(self.encoder):
+            out += [("%s/conv%d/kernel" % (s, n + 1), w), ("%s/conv%d/bias" % (s, n + 1), b)]
+        for l, cell in enumerate(self.rnn.cells):
+            base = "%s/rnn/rnn/multi_rnn_cell/cell_%d/ConvLSTMCell/" % (s, l)
+            out += [(base + "hidden_to_state_kernel", cell.hidden_to_state_kernel),
+                    (base + "input_to_state_kernel", cell.input_to_state_kernel), (base + "bias", cell.bias)]
+        out += [("%s/prediction/kernel" % s, self.dense_kernel), ("%s/prediction/bias" % s, self.dense_bias)]
+        return out
+
+    # -- forward -------------------------------------------------------------------------------
+    @property
+    def rnn_zero_state(self):
+        return lambda batch_size: self.rnn.zero_state(batch_size, self.device)
+
+    def _to_dev(self, a, dtype):
+        if torch.is_tensor(a):
+            return a.to(device=self.device, dtype=dtype)
+        return torch.as_tensor(np.asarray(a), device=self.device).to(dtype)
+
+    def _sequence_input(self, features, histories):
+        """histories: dense [B,T,P,P,hist] (the reference's feed) or int points [B,T,hist,2]."""
+        if self.history_length == 0:
+            B = features.shape[0]
+            pts = torch.zeros([B, self.max_timesteps, 0, 2], dtype=torch.int32, device=self.device)
+            return SequenceInput(static=features, hist_points=pts)
+        is_points = (torch.is_tensor(histories) and not histories.is_floating_point() and histories.dim() == 4) or \
+                    (not torch.is_tensor(histories) and np.asarray(histories).ndim == 4)
+        if is_points:
+            return SequenceInput(static=features, hist_points=self._to_dev(histories, torch.int32))
+        return SequenceInput(static=features, hist_dense=self._to_dev(histories, self.compute_dtype))
+
+    def encode(self, images):
+        x = self._to_dev(images, self.compute_dtype).contiguous()
+        for w, b in self.encoder:
+            x = conv2d_same_relu(x, w, b, self.compute_dtype)
+        return x
+
+    def head(self, rnn_out):
+        """rnn_out [B,T,P,P,F] -> logits [B,T,K] (reference History2LargeExperiment.py:48-50)."""
+        B, T, P = rnn_out.shape[0], rnn_out.shape[1], rnn_out.shape[2]
+        hs = self.head_size
+        if hs != P:
+            k = P // hs
+            rnn_out = rnn_out.reshape(B, T, hs, k, hs, k, -1).float().mean(dim=(3, 5)).to(self.compute_dtype)
+        flat = rnn_out.reshape(B * T, hs * hs * self.rnn_filters)
+        logits = torch.addmm(self.dense_bias.to(flat.dtype), flat, self.dense_kernel.to(flat.dtype))
+        return logits.reshape(B, T, self.num_classes)
+
+    def forward(self, images, durations, histories, initial_state=None):
+        features = self.encode(images)
+        seq = self._sequence_input(features, histories)
+        rnn_out, final = dynamic_rnn(self.rnn, seq, sequence_length=durations, initial_state=initial_state,
+                                     time_major=False)
+        self.rnn_final_state = final
+        self.prediction_logits = self.head(rnn_out)
+        return self.prediction_logits, final
+
+    @property
+    def prediction_max(self):
+        """(x, y) of the argmax class of the last evaluation (reference Model.py:91-94)."""
+        return decode.prediction_max(self.prediction_logits, self.head_size)
+
+    def _loss_and_metrics(self, logits, durations, targets):
+        targets = self._to_dev(targets, torch.int64)
+        dur = self._to_dev(durations, torch.int64)
+        B, T, K = logits.shape
+        dense = targets[..., 0] * self.head_size + targets[..., 1]  # x-major (Model.py:39)
+        loss = decode.softmax_xent_mean(logits, dense)
+        with torch.no_grad():
+            pred = decode.argmax_rows(logits)
+            mask = torch.arange(T, device=self.device)[None, :] < dur[:, None]
+            num = dur.sum()
+            acc = ((pred == dense) & mask).sum().double() / num
+            pm = torch.stack([pred // self.head_size, pred % self.head_size], dim=2)
+            err = (targets - pm).double().norm(dim=2) * mask.double()
+            metrics = dict(loss=loss.detach(), accuracy=acc, avg_error=err.sum() / num.double(), max_error=err.max())
+        return loss, metrics
+
+    # -- optimiser (reference Model.py:106-112) --------------------------------------------------
+    def _apply_gradients(self):
+        flat = self._flat_grad
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world = torch.distributed.get_world_size(self.process_group)
+            if world > 1:
+                torch.distributed.all_reduce(flat, group=self.process_group)
+                flat.div_(world)
+        # tf.clip_by_global_norm(grads, 1.0): scale = clip / max(norm, clip)
+        norm = flat.norm()
+        flat.mul_(1.0 / torch.clamp(norm, min=1.0))
+        self.global_step += 1
+        t = self.global_step
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        lr_t = self.learning_rate * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        grads = [p.grad for p in self.trainable_variables]
+        with torch.no_grad():
+            torch._foreach_mul_(self._adam_m, b1)
+            torch._foreach_add_(self._adam_m, grads, alpha=1 - b1)
+            torch._foreach_mul_(self._adam_v, b2)
+            torch._foreach_addcmul_(self._adam_v, grads, grads, value=1 - b2)
+            denom = torch._foreach_sqrt(self._adam_v)
+            torch._foreach_add_(denom, eps)
+            torch._foreach_addcdiv_(self.trainable_variables, self._adam_m, denom, value=-lr_t)
+        return norm
+
+    def train_step(self, images, durations, histories, targets):
+        """Forward, backward, clip, Adam. Returns the (device) loss tensor."""
+        self._flat_grad.zero_()
+        logits, _ = self.forward(images, durations, histories)
+        loss, metrics = self._loss_and_metrics(logits, durations, targets)
+        loss.backward()
+        self._apply_gradients()
+        self.loss = loss.detach()
+        self.last_metrics = metrics
+        return self.loss
+
+    # -- reference surface -----------------------------------------------------------------------
+    def train(self, images, durations, histories, targets, additional_feed_args={}):
+        self.train_step(images, durations, histories, targets)
+        self._add_summaries('train')
+
+    def validate(self, images, durations, histories, targets, additional_feed_args={}):
+        with torch.no_grad():
+            logits, _ = self.forward(images, durations, histories)
+            loss, metrics = self._loss_and_metrics(logits, durations, targets)
+        self.loss = loss
+        self.last_metrics = metrics
+        self._add_summaries('valid')
+
+    def _add_summaries(self, prefix, extra=None):
+        if self._filepath is None:
+            return
+        if self._events is None:
+            os.makedirs(self._filepath, exist_ok=True)
+            self._events = open(os.path.join(self._filepath, 'events.jsonl'), 'a')
+        rec = {"step": self.global_step, "time": time.time()}
+        for k, v in self.last_metrics.items():
+            rec["%s/%s" % (prefix, k)] = float(v)
+        if extra:
+            rec.update(extra)
+        self._events.write(json.dumps(rec) + "\n")
+        self._events.flush()
+
+    # checkpoints: torch state dict under TensorFlow-style names (reference Model.py:132-148)
+    def state_dict(self):
+        sd = {name: p.detach().cpu() for name, p in self._named_parameters()}
+        sd["global_step"] = torch.tensor(self.global_step)
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for name, p in self._named_parameters():
+                p.copy_(sd[name].to(self.device))
+        self.global_step = int(sd["global_step"])
+
+    def save(self):
+        os.makedirs(self._filepath, exist_ok=True)
+        path = os.path.join(self._filepath, 'model-%d.pt' % self.global_step)
+        torch.save(self.state_dict(), path)
+        with open(os.path.join(self._filepath, 'checkpoint'), 'w') as f:
+            f.write(os.path.basename(path))
+        keep = sorted((p for p in os.listdir(self._filepath) if p.startswith('model-') and p.endswith('.pt')),
+                      key=lambda s: int(s[6:-3]))
+        for old in keep[:-2]:  # max_to_keep=2
+            os.remove(os.path.join(self._filepath, old))
+
+    def maybe_restore(self):
+        if not os.path.exists(self._filepath):
+            os.makedirs(self._filepath)
+            print('No model found at {}'.format(self._filepath))
+        marker = os.path.join(self._filepath, 'checkpoint')
+        if os.path.exists(marker):
+            with open(marker) as f:
+                name = f.read().strip()
+            self.load_state_dict(torch.load(os.path.join(self._filepath, name), weights_only=True))
+            print('Restored model from {} at step {}'.format(self._filepath, self.global_step))
+
+    # -- autoregressive decode + IoU (reference Model.py:208-260) ---------------------------------
+    #: which predicted vertices enter the IoU polygon: the base class rasterises all max_timesteps
+    #: predictions (Model.py:253-255); the deep end-token experiment slices by duration.
+    iou_slice_by_duration = False
+    #: History0Experiment builds the predicted polygon from the predictions alone (its :158)
+    iou_prepend_history = True
+
+    def _stop_test(self, predicted, true_vertices, b):
+        """Close-on-first-vertex rule of the base class (Model.py:240)."""
+        return bool(np.all(predicted == true_vertices[b][-self.history_length]))
+
+    def decode(self, images, true_vertices):
+        """The reference's per-vertex loop: one recurrence step per iteration with the previous
+        state fed back, argmax decode, history shifted by np.roll(+1).  Returns
+        (predicted_vertices [B,T,2] float64, prediction_durations [B])."""
+        B = images.shape[0] if hasattr(images, "shape") else len(images)
+        T, P, hist = self.max_timesteps, self.prediction_size, self.history_length
+        predicted_vertices = np.empty([B, T, 2])
+        with torch.no_grad():
+            features = self.encode(images)
+            # frame i of the first step shows true_vertices[len - hist + i] (create_history with
+            # end_idx = len(v) - 1, Model.py:224-226)
+            pts = np.full([B, 1, max(hist, 1), 2], -1, np.int32)[:, :, :hist]
+            for b, v in enumerate(true_vertices):
+                n = len(v)
+                for i in range(hist):
+                    pts[b, 0, i] = v[(n - 1 - hist + i + 1) % n]
+            state = self.rnn.zero_state(B, self.device)
+            required = np.ones([B], dtype=np.uint32)
+            durations = np.zeros([B], dtype=np.uint32)
+            cells = list(self.rnn.cells)
+            for i in range(T):
+                seq = SequenceInput(static=features, hist_points=torch.as_tensor(pts, device=self.device))
+                seq.T = 1
+                dur_dev = torch.as_tensor(required.astype(np.int32), device=self.device)
+                out, final, _ = _run_sequence_forward(cells, seq, dur_dev, 1, [(s.c, s.h) for s in state], False)
+                state = tuple(LSTMStateTuple(c.clone(), h.clone()) for c, h in final)
+                logits = self.head(out)
+                xy = decode.prediction_max(logits, self.head_size)[:, 0].cpu().numpy()
+                predicted_vertices[:, i, :] = xy
+                durations += required
+                frame = xy.copy()
+                for b in range(B):
+                    frame[b] = self._update_after_prediction(predicted_vertices, frame[b], true_vertices, b, i,
+                                                             required)
+                if hist > 0:
+                    pts = np.roll(pts, 1, axis=2)
+                    pts[:, 0, -1] = frame
+        self.rnn_final_state = state
+        return predicted_vertices, durations
+
+    def _update_after_prediction(self, predicted_vertices, xy, true_vertices, b, i, required):
+        """Stop rule of the base class (Model.py:239-249): returns the point shown in the next
+        history frame."""
+        if self._stop_test(predicted_vertices[b, i, :], true_vertices, b):
+            required[b] = 0
+        return xy
+
+    def validate_iou(self, images, true_vertices, summary_prefix='valid', additional_feed_args={}):
+        predicted_vertices, durations = self.decode(images, true_vertices)
+        P, hist = self.prediction_size, self.history_length
+        scale = P // self.head_size
+        pred_polys = []
+        for b in range(len(true_vertices)):
+            pv = predicted_vertices[b][:durations[b]] if self.iou_slice_by_duration else predicted_vertices[b]
+            pv = pv * scale
+            if self.iou_prepend_history and hist > 0:
+                pv = np.concatenate([np.asarray(true_vertices[b])[-hist:], pv], axis=0)
+            pred_polys.append(pv.astype(np.int64))
+        vmax = max(max(len(p) for p in pred_polys), max(len(v) for v in true_vertices), util.VMAX_DEFAULT)
+        vp, nvp = util.pack_polygons(pred_polys, vmax=vmax)
+        vt, nvt = util.pack_polygons([np.asarray(v) for v in true_vertices], vmax=vmax)
+        dev = self.device
+        inter, union = util.raster_iou(torch.from_numpy(vp).to(dev), torch.from_numpy(nvp).to(dev),
+                                       torch.from_numpy(vt).to(dev), torch.from_numpy(nvt).to(dev), P)
+        ious = (inter.double() / union.double()).cpu().numpy()
+        self.last_ious = ious
+        self.last_predicted_vertices = predicted_vertices
+        self.last_prediction_durations = durations
+        tag = summary_prefix + '/iou' if summary_prefix else 'iou'
+        self._add_summaries(summary_prefix or 'valid', extra={tag: float(np.mean(ious))})
+        return float(np.mean(ious))

@@ -1,0 +1,79 @@
+"""Softmax cross-entropy, argmax and sampling over the vertex class grid, on the libisg kernels
+(isg_softmax_xent_fwd / _bwd, isg_argmax_rows, isg_sample_rows)."""
+import torch
+
+from .. import _lib
+from ..ops import dtype_code
+
+
+def _rows(logits):
+    cols = logits.shape[-1]
+    z = logits.reshape(-1, cols)
+    if z.dtype not in (torch.float32, torch.bfloat16):
+        z = z.float()
+    return z.contiguous(), z.shape[0], cols
+
+
+class _XentRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weights):
+        z, rows, cols = _rows(logits)
+        lab = labels.reshape(-1).to(torch.int32).contiguous()
+        w = weights.reshape(-1).to(torch.float32).contiguous() if weights is not None else None
+        loss = torch.empty([rows], dtype=torch.float32, device=z.device)
+        lse = torch.empty([rows], dtype=torch.float32, device=z.device)
+        rc = _lib.lib().isg_softmax_xent_fwd(_lib.ptr(z), _lib.ptr(lab), _lib.ptr(w), rows, cols, dtype_code(z.dtype),
+                                             _lib.ptr(loss), _lib.ptr(lse), None, _lib.current_stream())
+        _lib.check(rc, "isg_softmax_xent_fwd")
+        ctx.save_for_backward(z, lab, lse, w)
+        ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
+        return loss.reshape(logits.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z, lab, lse, w = ctx.saved_tensors
+        rows, cols = z.shape
+        scale = dloss.reshape(-1).to(torch.float32)
+        if w is not None:
+            scale = scale * w
+        scale = scale.contiguous()
+        dz = torch.empty_like(z)
+        rc = _lib.lib().isg_softmax_xent_bwd(_lib.ptr(z), _lib.ptr(lab), _lib.ptr(lse), _lib.ptr(scale), 1.0, rows,
+                                             cols, dtype_code(z.dtype), _lib.ptr(dz), _lib.current_stream())
+        _lib.check(rc, "isg_softmax_xent_bwd")
+        return dz.reshape(ctx.shape).to(ctx.in_dtype), None, None
+
+
+def softmax_xent_rows(logits, labels, weights=None):
+    """Per-row sparse softmax cross-entropy (optionally times a per-row weight)."""
+    return _XentRows.apply(logits, labels, weights)
+
+
+def softmax_xent_mean(logits, labels, weights=None):
+    """mean over every row (reference polyrnn/Model.py:98-100)."""
+    return softmax_xent_rows(logits, labels, weights).mean()
+
+
+def argmax_rows(logits):
+    """int64 argmax over the last axis, first maximum wins (tf.argmax)."""
+    z, rows, cols = _rows(logits)
+    out = torch.empty([rows], dtype=torch.int32, device=z.device)
+    rc = _lib.lib().isg_argmax_rows(_lib.ptr(z), rows, cols, dtype_code(z.dtype), _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_argmax_rows")
+    return out.to(torch.int64).reshape(logits.shape[:-1])
+
+
+def prediction_max(logits, prediction_size):
+    """[..., 2] = (argmax // P, argmax % P), i.e. (x, y) (reference polyrnn/Model.py:91-94)."""
+    a = argmax_rows(logits)
+    return torch.stack([a // prediction_size, a % prediction_size], dim=-1)
+
+
+def sample_rows(logits, seed, row_offset=0):
+    """One categorical sample per row of softmax(logits) (tf.multinomial's role)."""
+    z, rows, cols = _rows(logits)
+    out = torch.empty([rows], dtype=torch.int32, device=z.device)
+    rc = _lib.lib().isg_sample_rows(_lib.ptr(z), rows, cols, dtype_code(z.dtype), int(seed), int(row_offset),
+                                    _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_sample_rows")
+    return out.to(torch.int64).reshape(logits.shape[:-1])

@@ -135,6 +135,29 @@ int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B,
                        int dtype, const int32_t* durations, int t, void* workspace, int accumulate, float* dw_x,
                        float* dw_h, float* dbias, void* stream);
 
+/* ---- vertex decoding over the class grid ----------------------------------------------------
+ * logits: `dtype` [rows][cols] (cols = P*P or P*P + 1).  One wave per row.
+ *
+ * isg_softmax_xent_fwd replaces tf.nn.sparse_softmax_cross_entropy_with_logits (reference
+ * polyrnn/Model.py:98-99; weighted by td_target in polyrl/ReinforceOverfitExperiment.py:47-48) and, in
+ * the same pass, tf.argmax(logits, axis=2) with its first-maximum rule (reference polyrnn/Model.py:44).
+ *   labels int32 [rows]; weights float [rows] or NULL; any of loss_rows / lse_rows / argmax_rows
+ *   (float, float, int32 [rows]) may be NULL.  loss_rows[r] = (lse - logit[label]) * weights[r].
+ * isg_softmax_xent_bwd: dlogits[r][c] = (softmax[r][c] - [c == label[r]]) * row_scale[r] * scale
+ *   (row_scale may be NULL) - the gradient tf.gradients derives for the loss above.
+ * isg_sample_rows replaces tf.multinomial(logits - max, 1) (reference
+ *   polyrl/ReinforceOverfitExperiment.py:101-103): one categorical draw per row by the Gumbel-max
+ *   rule from a counter-based generator keyed by (seed, row_offset + row, column).  Same
+ *   distribution as the reference, not the same random stream.
+ */
+int isg_softmax_xent_fwd(const void* logits, const int32_t* labels, const float* weights, int rows, int cols,
+                         int dtype, float* loss_rows, float* lse_rows, int32_t* argmax_rows, void* stream);
+int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, const float* lse_rows, const float* row_scale,
+                         float scale, int rows, int cols, int dtype, void* dlogits, void* stream);
+int isg_argmax_rows(const void* logits, int rows, int cols, int dtype, int32_t* out_idx, void* stream);
+int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                    unsigned long long row_offset, int32_t* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
-"""Shared builders for ConvLSTM tests: random parameters and a float64 torch re-expression of the
-reference graph (F.conv2d + autograd), used to cross-check the NumPy oracle."""
+"""Shared builders for ConvLSTM tests: random parameters and batches; the float64 torch re-expression
+of the reference graph used to cross-check the NumPy oracle lives in oracle/torch_port.py."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -56,47 +56,9 @@ def t64(a):
     return torch.tensor(np.asarray(a), dtype=torch.float64)
 
 
-def torch_conv_same(x, w, b=None):
-    """x [B,H,W,C] float64 tensor, w HWIO tensor -> [B,H,W,O]; TensorFlow SAME padding."""
-    kh, kw = w.shape[0], w.shape[1]
-    pt, pl = (kh - 1) // 2, (kw - 1) // 2
-    xp = F.pad(x.permute(0, 3, 1, 2), (pl, kw - 1 - pl, pt, kh - 1 - pt))
-    y = F.conv2d(xp, w.permute(3, 2, 0, 1), b)
-    return y.permute(0, 2, 3, 1)
-
-
-def torch_cell(x, c, h, w_x, w_h, bias):
-    y = torch_conv_same(h, w_h) + torch_conv_same(x, w_x) + bias
-    j, i, f, o = torch.split(y, y.shape[3] // 4, dim=3)
-    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(j)
-    return torch.sigmoid(o) * torch.tanh(c2), c2
-
-
-def torch_model_logits(tp, images, histories, durations):
-    """tp: params as float64 tensors (same nesting). Returns logits [B,T,K] and final state."""
-    x = images
-    for p in tp["encoder"]:
-        x = torch.relu(torch_conv_same(x, p["w"], p["b"]))
-    B, T = histories.shape[:2]
-    Fh = tp["rnn"][0]["w_h"].shape[2]
-    P = x.shape[1]
-    state = [(torch.zeros(B, P, P, Fh, dtype=torch.float64), torch.zeros(B, P, P, Fh, dtype=torch.float64))
-             for _ in tp["rnn"]]
-    outs = []
-    for t in range(T):
-        live = (t < durations).to(torch.float64)[:, None, None, None]
-        inp = torch.cat([x, histories[:, t]], dim=3)
-        new_state = []
-        for l, p in enumerate(tp["rnn"]):
-            c_prev, h_prev = state[l]
-            h, c = torch_cell(inp, c_prev, h_prev, p["w_x"], p["w_h"], p["bias"])
-            new_state.append((live * c + (1 - live) * c_prev, live * h + (1 - live) * h_prev))
-            inp = h
-        outs.append(live * inp)
-        state = new_state
-    rnn_out = torch.stack(outs, dim=1)
-    logits = rnn_out.reshape(B * T, -1) @ tp["dense"]["w"] + tp["dense"]["b"]
-    return logits.reshape(B, T, -1), state
+from oracle.torch_port import cell as torch_cell  # noqa: E402,F401
+from oracle.torch_port import conv_same as torch_conv_same  # noqa: E402,F401
+from oracle.torch_port import model_logits as torch_model_logits  # noqa: E402,F401
 
 
 def params_to_torch(params, requires_grad=True):
