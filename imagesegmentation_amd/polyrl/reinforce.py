@@ -1,0 +1,215 @@
+"""REINFORCE on the polygon environments (reference polyrl/ReinforceOverfitExperiment.py and
+polyrl/ReinforceOverfitEndTokenExperiment.py).
+
+``ExperimentPolicyEstimator`` keeps the reference's surface - ``predict(image, history, rnn_state)``,
+``update(images, histories, actions, td_targets, apply_grads)``, ``get_rnn_zero_state(batch_size)`` -
+and its semantics: the History2Large network with P*P (+1) action logits, actions sampled from the
+first time step's logits, loss = mean over [B, T] of cross-entropy(action) * td_target with padded
+steps weighted 0, raw (unclipped) gradients summed into a buffer and applied by Adam when asked
+(reference :111-134, :147-176).  ``reinforce`` is the reference's episode loop (:279-331).
+
+``BatchedReinforce`` runs the same algorithm for N lock-stepped rollouts per GPU: one recurrent step
+for all environments per launch, actions from isg_sample_rows, terminal IoU rewards of every rollout
+from one isg_raster_iou launch, one teacher-forced update pass over the recorded episodes, gradients
+all-reduced across ranks (RCCL) before Adam.  Episodes of one update are the batch: their
+per-episode gradients are summed exactly as the reference sums them in its gradBuffer.
+"""
+import itertools
+import math
+
+import numpy as np
+import torch
+
+from ..convLSTM import LSTMStateTuple, SequenceInput, _run_sequence_forward
+from ..polyrnn import decode
+from ..polyrnn.Model import Model
+from .batched_env import BatchedPolygonEnv
+
+
+def discount_rewards(r, gamma=0.99):
+    """Reverse cumulative discounted return (reference polyrl/MonteCarloPolicyGradient.py:13-22)."""
+    r = np.asarray(r, dtype=np.float64)
+    out = np.zeros_like(r)
+    running = 0.0
+    for t in reversed(range(r.size)):
+        running = running * gamma + r[t]
+        out[t] = running
+    return out
+
+
+class ExperimentPolicyEstimator(Model):
+    encoder_spec = ((16, 5), (16, 5), (16, 3))
+    rnn_layers = 2
+    scope_name = 'policy_estimator'
+
+    def __init__(self, image_size, action_size, tf_session=None, summary_writer=None, max_timesteps=10,
+                 end_token=False, **kwargs):
+        self.end_token = end_token
+        self.action_size = action_size
+        self.tf_session = tf_session
+        self.summary_writer = summary_writer
+        self._sample_seed = kwargs.pop("sample_seed", 0)
+        self._sample_calls = 0
+        super().__init__(tf_session, max_timesteps, image_size, action_size, 2, kwargs.pop("filepath", None), **kwargs)
+        self.gradBuffer = torch.zeros_like(self._flat_grad)
+
+    # -- acting ----------------------------------------------------------------------------------
+    def get_rnn_zero_state(self, batch_size):
+        return self.rnn.zero_state(batch_size, self.device)
+
+    def step_logits(self, features, history_points, rnn_state):
+        """One recurrent step for a batch: features [B,P,P,Cf], history_points int [B,hist,2].
+        Returns (logits [B,K], new state)."""
+        seq = SequenceInput(static=features, hist_points=history_points[:, None].contiguous())
+        out, final, _ = _run_sequence_forward(list(self.rnn.cells), seq, None, 1, [(s.c, s.h) for s in rnn_state], False)
+        state = tuple(LSTMStateTuple(c.clone(), h.clone()) for c, h in final)
+        return self.head(out)[:, 0], state
+
+    def sample_actions(self, logits):
+        """Categorical sample per row -> (x, y) = (a // P, a % P); the end token is class P*P = (P, 0)."""
+        a = decode.sample_rows(logits, self._sample_seed, row_offset=self._sample_calls * (1 << 20))
+        self._sample_calls += 1
+        return torch.stack([a // self.action_size, a % self.action_size], dim=1)
+
+    def predict(self, image, history, rnn_state):
+        """Picks a single action given image [P,P,3] and history frames [P,P,hist] (reference :136-145).
+        Returns (action [2], new rnn state)."""
+        with torch.no_grad():
+            features = self.encode(np.asarray(image)[None])
+            pts = np.full([1, self.history_length, 2], -1, np.int32)
+            h = np.asarray(history)
+            for i in range(self.history_length):
+                ys, xs = np.nonzero(h[:, :, i])
+                if len(xs):
+                    pts[0, i] = (xs[0], ys[0])
+            logits, state = self.step_logits(features, torch.as_tensor(pts, device=self.device), rnn_state)
+            action = self.sample_actions(logits)[0].cpu().numpy()
+        return action, state
+
+    # -- learning ----------------------------------------------------------------------------------
+    def policy_loss(self, images, durations, histories, actions, td_targets):
+        """mean over [B, T] of xent(action) * td (reference :45-48)."""
+        logits, _ = self.forward(images, durations, histories)
+        actions = self._to_dev(actions, torch.int64)
+        dense = actions[..., 0] * self.action_size + actions[..., 1]
+        td = self._to_dev(td_targets, torch.float32)
+        return decode.softmax_xent_rows(logits, dense, td).mean()
+
+    def apply_accumulated(self, all_reduce=True):
+        """Adam on the summed raw gradients (reference ``update_batch``, :130-131, :171-177)."""
+        self._flat_grad.copy_(self.gradBuffer)
+        self._apply_gradients(clip=False, all_reduce=all_reduce, average=False)
+        self.gradBuffer.zero_()
+
+    def update(self, images, histories, actions, td_targets, apply_grads):
+        """One episode (reference :147-177): images [P,P,3], histories [n,P,P,hist], actions [n,2],
+        td_targets [n]; pads to max_timesteps, accumulates the gradient, applies it when asked."""
+        T, P, hist = self.max_timesteps, self.action_size, self.history_length
+        n = np.asarray(histories).shape[0]
+        td = np.concatenate([np.asarray(td_targets, np.float64), np.zeros([T - n])])[None]
+        at = np.concatenate([np.asarray(actions), np.zeros([T - n, 2])], axis=0)[None]
+        h = np.concatenate([np.asarray(histories), np.zeros([T - n, P, P, hist])], axis=0)[None]
+        self._flat_grad.zero_()
+        loss = self.policy_loss(np.asarray(images)[None], np.array([n]), h, at, td)
+        loss.backward()
+        self.gradBuffer += self._flat_grad
+        if apply_grads:
+            self.apply_accumulated()
+        return float(loss)
+
+
+def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_per_episode=None, summary_writer=None,
+              validate_every=None):
+    """The reference's scalar episode loop (polyrl/ReinforceOverfitExperiment.py:279-331).
+    Returns the list of episode rewards."""
+    total_reward = []
+    episodes = range(total_episodes) if total_episodes is not None else itertools.count()
+    for episode_num in episodes:
+        state = env.reset()
+        image = state[:, :, :3]
+        ep_history = []
+        total_episode_reward = 0
+        rnn_state = policy_estimator.get_rnn_zero_state(batch_size=1)
+        steps = range(max_timesteps_per_episode) if max_timesteps_per_episode is not None else itertools.count()
+        reward = 0
+        for timestep in steps:
+            histories = state[:, :, 3:]
+            action, next_rnn_state = policy_estimator.predict(image=image, history=histories, rnn_state=rnn_state)
+            next_state, reward, done = env.step(action)
+            total_episode_reward += reward
+            ep_history.append([state, action, reward, next_state, done, rnn_state])
+            state = next_state
+            rnn_state = next_rnn_state
+            if done:
+                break
+        if reward > 0:  # update only when the episode saw any reward (reference :306)
+            rewards = discount_rewards([e[2] for e in ep_history])
+            h = np.stack([e[0][:, :, 3:] for e in ep_history], axis=0)
+            policy_estimator.update(images=image, histories=h, actions=np.vstack([e[1] for e in ep_history]),
+                                    td_targets=rewards, apply_grads=episode_num % 5 == 0 and episode_num != 0)
+        total_reward.append(total_episode_reward)
+    return total_reward
+
+
+class BatchedReinforce:
+    """N lock-stepped REINFORCE rollouts per GPU against a BatchedPolygonEnv."""
+
+    def __init__(self, policy, dataset, num_envs, gamma=0.99):
+        self.policy = policy
+        self.env = BatchedPolygonEnv(dataset, num_envs, end_token=policy.end_token, max_steps=policy.max_timesteps,
+                                     device=policy.device, state_dtype=torch.float32)
+        self.num_envs = num_envs
+        self.gamma = gamma
+
+    def rollout(self, images=None, polygons=None):
+        """Runs every environment for up to max_timesteps sampled actions.  Returns a dict with the
+        recorded episode (history points, actions, lengths), rewards (float64 [N]) and counts."""
+        pol, env = self.policy, self.env
+        N, T, hist = self.num_envs, pol.max_timesteps, pol.history_length
+        env.reset(images=images, polygons=polygons)
+        dev = pol.device
+        points = torch.full([N, T, hist, 2], -1, dtype=torch.int32, device=dev)
+        actions = torch.zeros([N, T, 2], dtype=torch.int32, device=dev)
+        lengths = torch.zeros([N], dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            features = pol.encode(env.image)
+            state = pol.get_rnn_zero_state(N)
+            for t in range(T):
+                active = ~env.done
+                points[:, t] = env.history_points
+                logits, state = pol.step_logits(features, env.history_points, state)
+                a = pol.sample_actions(logits).to(torch.int32)
+                actions[:, t] = a
+                lengths += active.to(torch.int32)
+                env.step(a, compute_reward=False)
+            reward, inter, union = env.terminal_rewards()
+            # an episode that never terminated earns nothing (the scalar loop ends it with reward 0)
+            reward = torch.where(env.done, reward, torch.zeros_like(reward))
+        return dict(images=env.image, points=points, actions=actions, lengths=lengths, reward=reward, inter=inter,
+                    union=union, done=env.done.clone())
+
+    def returns(self, ep):
+        """Discounted return per step: the only non-zero reward is the terminal one, so
+        G_t = gamma^(len-1-t) * reward for t < len, 0 after."""
+        T = self.policy.max_timesteps
+        t = torch.arange(T, device=self.policy.device)[None, :]
+        n = ep["lengths"][:, None]
+        g = torch.pow(torch.tensor(self.gamma, dtype=torch.float64, device=self.policy.device),
+                      (n - 1 - t).clamp(min=0).double()) * ep["reward"][:, None]
+        return torch.where(t < n, g, torch.zeros_like(g)).float()
+
+    def update(self, ep):
+        """One accumulate-and-apply over all episodes of the batch (sum of per-episode gradients)."""
+        pol = self.policy
+        pol._flat_grad.zero_()
+        td = self.returns(ep)
+        loss = pol.policy_loss(ep["images"], ep["lengths"], ep["points"], ep["actions"], td) * self.num_envs
+        loss.backward()
+        pol.gradBuffer += pol._flat_grad
+        pol.apply_accumulated()
+        return loss.detach() / self.num_envs
+
+    def step(self, images=None, polygons=None):
+        ep = self.rollout(images, polygons)
+        loss = self.update(ep)
+        return ep, loss

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import util
+from .. import parallel, util
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, SequenceInput, _run_sequence_forward, dynamic_rnn
 from . import decode
 
@@ -62,6 +62,7 @@ class Model:
     rnn_layers = 2
     rnn_filters = 16
     end_token = False
+    scope_name = 'Estimator'
 
     def __init__(self, sess, max_timesteps, image_size, prediction_size, history_length, filepath,
                  compute_dtype=torch.float32, device=None, seed=0, head_size=None, learning_rate=1e-4,
@@ -87,7 +88,6 @@ class Model:
         self.learning_rate = learning_rate
         self.process_group = process_group
         self.global_step = 0
-        self.scope_name = 'Estimator'
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
         self._named = {}
@@ -223,16 +223,15 @@ class Model:
         return loss, metrics
 
     # -- optimiser (reference Model.py:106-112) --------------------------------------------------
-    def _apply_gradients(self):
+    def _apply_gradients(self, clip=True, all_reduce=True, average=True):
+        """All-reduce of the flat gradient bucket across ranks (one RCCL collective), global-norm
+        clip of the reduced gradient, TensorFlow-form Adam."""
         flat = self._flat_grad
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            world = torch.distributed.get_world_size(self.process_group)
-            if world > 1:
-                torch.distributed.all_reduce(flat, group=self.process_group)
-                flat.div_(world)
-        # tf.clip_by_global_norm(grads, 1.0): scale = clip / max(norm, clip)
+        if all_reduce:
+            parallel.allreduce_gradients_(flat, self.process_group, average=average)
         norm = flat.norm()
-        flat.mul_(1.0 / torch.clamp(norm, min=1.0))
+        if clip:  # tf.clip_by_global_norm(grads, 1.0): scale = clip / max(norm, clip)
+            flat.mul_(1.0 / torch.clamp(norm, min=1.0))
         self.global_step += 1
         t = self.global_step
         b1, b2, eps = 0.9, 0.999, 1e-8
