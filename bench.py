@@ -94,8 +94,10 @@ def time_kernels(model, batch, dtype_name):
     F = 16
     out = []
     for l, cell in enumerate(model.rnn.cells):
-        packed = cell.packed()
+        hist = model.history_length if l == 0 else 0  # layer 0 takes its history frames as points
+        packed = cell.packed(hist=hist)
         cs, c_real = packed.cs, cell.input_to_state_kernel.shape[2]
+        pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
         x = torch.randn([B, P, P, cs], device=dev).to(dt)
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
         c = torch.randn([B, P, P, F], device=dev)
@@ -114,11 +116,13 @@ def time_kernels(model, batch, dtype_name):
         esz = 2 if dt == torch.bfloat16 else 4
         px = B * P * P
         kernels = [
-            ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates), flops, "mfma"),
+            ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts), flops,
+             "mfma"),
             ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
              px * (2 * 4 * F * esz + 2 * F * esz + 4 * F * 4), "hbm"),
             ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, "mfma"),
-            ("wgrad", lambda: ops.wgrad(x, h, dy, c_real, dwx, dwh, db, accumulate=False), flops, "mfma"),
+            ("wgrad", lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, accumulate=False, hist_points=pts, hist=hist),
+             flops, "mfma"),
         ]
         for name, fn, work, bound in kernels:
             ms = event_time_ms(fn, 5)

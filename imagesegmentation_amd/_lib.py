@@ -26,16 +26,16 @@ SIGNATURES = {
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
     "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
-    "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
-    "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp,
-                                     _vp, _vp, _ll, _vp, _vp]),
+    "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
+                                     _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
     "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _int, _int, _int, _int, _int, _vp, _int,
                                           _vp, _vp, _vp]),
     "isg_convlstm_dgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _int, _int, _vp,
                                   _vp]),
     "isg_convlstm_wgrad_workspace_bytes": (_ll, [_int, _int]),
-    "isg_convlstm_wgrad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _vp,
-                                  _vp, _vp, _vp]),
+    "isg_convlstm_wgrad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _ll,
+                                  _vp, _int, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

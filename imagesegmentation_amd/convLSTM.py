@@ -96,14 +96,15 @@ class ConvLSTMCell(torch.nn.Module):
         return LSTMStateTuple(torch.zeros(shape, dtype=torch.float32, device=device),
                               torch.zeros(shape, dtype=self.compute_dtype, device=device))
 
-    def packed(self):
-        """Operand images of the current weights; rebuilt whenever a parameter changed in place."""
+    def packed(self, hist=0):
+        """Operand images of the current weights; rebuilt whenever a parameter changed in place.
+        ``hist`` trailing input channels are one-hot history frames handled as a tap scatter."""
         params = (self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias)
-        key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype,)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype, hist)
         if self._packed is None or self._packed_key != key:
-            cs = ops.padded_channels(self.input_to_state_kernel.shape[2], self.compute_dtype)
+            cs = ops.padded_channels(self.input_to_state_kernel.shape[2] - hist, self.compute_dtype)
             self._packed = ops.PackedWeights(self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias, cs,
-                                             self.compute_dtype)
+                                             self.compute_dtype, hist=hist)
             self._packed_key = key
         return self._packed
 
@@ -210,31 +211,41 @@ class SequenceInput:
         self._buf = None
         self._buf_t = None
 
+    @property
+    def scatter_hist(self):
+        """History given as points: the cell takes the frames as a 9-tap weight scatter and the
+        GEMM input is the static features alone."""
+        return self.x_seq is None and self.hist_points is not None and self.hist > 0
+
+    def layer0_packed(self, cell):
+        return cell.packed(hist=self.hist if self.scatter_hist else 0)
+
     def prepare(self, dtype, cs):
         self.dtype, self.cs = dtype, cs
         if self.x_seq is not None:
             return
         cf = self.static.shape[-1]
-        self._buf = torch.zeros([self.B, self.H, self.W, cs], dtype=dtype, device=self.static.device)
-        self._buf[..., :cf] = self.static.to(dtype)
         if self.hist_points is not None:
             self.hist_points = self.hist_points.to(torch.int32).contiguous()
+        if cf == cs and self.static.dtype == dtype and self.static.is_contiguous() and (self.scatter_hist or
+                                                                                         self.hist == 0):
+            self._buf = self.static.detach()
+            return
+        self._buf = torch.zeros([self.B, self.H, self.W, cs], dtype=dtype, device=self.static.device)
+        self._buf[..., :cf] = self.static.to(dtype)
+
+    def points(self, t):
+        """int32 [B, hist, 2] view of step t's frame points (scatter mode), else None."""
+        return self.hist_points[:, t] if self.scatter_hist else None
 
     def get(self, t):
         """[B, H, W, Cs] input of step t, valid until the next call."""
         if self.x_seq is not None:
             return _pad_channels(self.x_seq[t].to(self.dtype), self.cs)
-        if self._buf_t == t or self.hist == 0:
+        if self._buf_t == t or self.hist == 0 or self.scatter_hist:
             return self._buf
         cf = self.static.shape[-1]
-        if self.hist_dense is not None:
-            self._buf[..., cf:cf + self.hist] = self.hist_dense[:, t].to(self.dtype)
-        else:
-            from . import _lib
-            pts = self.hist_points[:, t].contiguous()
-            rc = _lib.lib().isg_history_frames(_lib.ptr(pts), self.B, self.H, self.hist, ops.dtype_code(self.dtype),
-                                               _lib.ptr(self._buf), self.cs, cf, _lib.current_stream())
-            _lib.check(rc, "isg_history_frames")
+        self._buf[..., cf:cf + self.hist] = self.hist_dense[:, t].to(self.dtype)
         self._buf_t = t
         return self._buf
 
@@ -245,7 +256,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
     dt = cells[0].compute_dtype
     B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
     dev = init_state[0][0].device
-    packed = [c.packed() for c in cells]
+    packed = [seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
     seq.prepare(dt, packed[0].cs)
     n_keep = T + 1 if save else 2
     Hs = [torch.empty([n_keep, B, H, W, F], dtype=dt, device=dev) for _ in range(L)]
@@ -262,7 +273,8 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
         for l in range(L):
             ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
                          out=out[:, t] if l == L - 1 else None, out_batch_stride=T * H * W * F,
-                         save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None)
+                         save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
+                         hist_points=seq.points(t) if l == 0 else None)
             x = Hs[l][nxt]
         cur = nxt
     final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
@@ -332,8 +344,8 @@ class _SequenceFunction(torch.autograd.Function):
                     above, stride = dx_mid, H * W * F
                 ops.pointwise_bwd(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l],
                                   durations_dev, t, dy=dy, dc_prev=dc_state[l])
-                c_real = cells[l].input_to_state_kernel.shape[2]
-                ops.wgrad(x_in, Hs[l][t], dy, c_real, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t)
+                ops.wgrad(x_in, Hs[l][t], dy, packed[l].c, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t,
+                          hist_points=seq.points(t) if l == 0 else None, hist=packed[l].hist)
                 if l > 0:
                     ops.dgrad(dy, packed[l], dh_state[l], dx=dx_mid, dx_channels=F, durations=durations_dev, t=t)
                 elif seq.x_seq is not None:

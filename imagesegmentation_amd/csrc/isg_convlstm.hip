@@ -13,77 +13,11 @@
 // tile with a 1-pixel halo staged in LDS once and reused by all 9 taps; workgroups are persistent
 // over tiles so the weight image is loaded into LDS once per workgroup (bf16) or streamed from L2
 // (f32, whose MFMA is 16x slower and needs no LDS residency).
-#include <hip/hip_bf16.h>
+#include "isg_convlstm_shared.h"
 
-#include "isg_common.h"
+using namespace isgc;
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
-constexpr int TH = 8, TW = 32;             // output tile
-constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
-constexpr int NPX = HALO_W * HALO_H;       // staged input pixels per tile
-constexpr int F_ = 16;                     // hidden channels (every runnable reference net)
-constexpr int NG = 4 * F_;                 // gate columns
-constexpr int kWgradMaxBlocks = 256;       // partial-sum slabs per weight-gradient launch
-
-template <typename T>
-struct Tr;
-
-template <>
-struct Tr<float> {
-    static constexpr int KG = 1;      // k values a lane feeds per MFMA
-    static constexpr int CHUNK = 4;   // elements per 16-byte staging chunk
-    static constexpr int PAD = 4;     // bytes added to an LDS pixel row (bank spread)
-    static constexpr int DTYPE = ISG_F32;
-    static constexpr bool W_IN_LDS = false;
-    using frag = float;
-    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ float to_f(float v) { return v; }
-    static __device__ __forceinline__ float from_f(float v) { return v; }
-    static __device__ __forceinline__ float ex(float v) { return expf(v); }
-};
-
-template <>
-struct Tr<__bf16> {
-    static constexpr int KG = 8;
-    static constexpr int CHUNK = 8;
-    static constexpr int PAD = 16;
-    static constexpr int DTYPE = ISG_BF16;
-    static constexpr bool W_IN_LDS = true;
-    using frag = bf16x8;
-    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ float to_f(__bf16 v) { return (float)v; }
-    static __device__ __forceinline__ __bf16 from_f(float v) { return (__bf16)v; }
-    static __device__ __forceinline__ float ex(float v) { return __expf(v); }
-};
-
-template <typename T>
-__device__ __forceinline__ float sigmoid_t(float z) {
-    return 1.0f / (1.0f + Tr<T>::ex(-z));
-}
-template <typename T>
-__device__ __forceinline__ float tanh_t(float z) {
-    // 1 - 2 / (exp(2z) + 1); saturates cleanly at +-1 for large |z|
-    return 1.0f - 2.0f / (Tr<T>::ex(2.0f * z) + 1.0f);
-}
-
-// Reference gate column (j|i|f|o blocks of F) held by row R of the forward weight image.
-__host__ __device__ inline int fwd_row_to_col(int R) {
-    const int t = R >> 5, r = R & 31;
-    const int gate = r & 3, hh = (r >> 2) & 1, a = r >> 3;
-    return gate * F_ + 8 * hh + 4 * t + a;
-}
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -93,9 +27,10 @@ __host__ __device__ inline int fwd_row_to_col(int R) {
 // channels of one tap: tap = g / GPT, first channel = (g % GPT) * KG.
 //   forward image: rows = 64 permuted gate columns, channels = [x (Cs) | h (F)]
 //   dgrad image  : rows = input channels [x (Cs) | h (F)] padded to 32*MT, channels of a tap = the
-//                  64 gate columns in the kernels' (channel, gate) order; taps are flipped.
+//                  64 gate columns in the kernels' (channel, gate) order; taps are flipped.  This one
+//                  is stored row-tile-major, [t][s][lane][KG], so that a launch can take one tile.
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* __restrict__ w_h, int C, int Cs,
+__global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* __restrict__ w_h, int C, int Cw, int Cs,
                                     int kind, int MT, T* __restrict__ out, long long total) {
     constexpr int KG = Tr<T>::KG;
     const int cpt = kind == 0 ? Cs + F_ : NG;  // channels per tap on the K side
@@ -106,8 +41,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* 
         long long r = idx / KG;
         const int lane = (int)(r % 64);
         r /= 64;
-        const int t = (int)(r % MT);
-        const int s = (int)(r / MT);
+        int t, s;
+        if (kind == 0) {
+            t = (int)(r % MT);
+            s = (int)(r / MT);
+        } else {
+            const long long ns = total / ((long long)KG * 64 * MT);
+            s = (int)(r % ns);
+            t = (int)(r / ns);
+        }
         const int R = 32 * t + (lane & 31);
         const int g = 2 * s + (lane >> 5);
         const int tap = g / gpt;
@@ -116,13 +58,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* 
         if (tap < 9) {
             if (kind == 0) {
                 const int col = fwd_row_to_col(R);
-                if (kc < C) v = w_x[((size_t)tap * C + kc) * NG + col];
+                if (kc < C) v = w_x[((size_t)tap * Cw + kc) * NG + col];
                 else if (kc >= Cs) v = w_h[((size_t)tap * F_ + (kc - Cs)) * NG + col];
             } else {
                 const int ch = kc >> 2, gate = kc & 3;  // dY channel order: [channel][gate]
                 const int col = gate * F_ + ch;
                 const int ftap = 8 - tap;               // flipped tap
-                if (R < C) v = w_x[((size_t)ftap * C + R) * NG + col];
+                if (R < C) v = w_x[((size_t)ftap * Cw + R) * NG + col];
                 else if (R >= Cs && R < Cs + F_) v = w_h[((size_t)ftap * F_ + (R - Cs)) * NG + col];
             }
         }
@@ -133,30 +75,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* 
 // ---------------------------------------------------------------------------------------------
 // shared pieces of the two convolution-shaped kernels
 // ---------------------------------------------------------------------------------------------
-struct ConvParams {
-    const void* in0;  // [B,H,W,c0]
-    const void* in1;  // [B,H,W,c1] or null (c1 = 0)
-    int c0, c1;
-    int B, H, W;
-    const void* wimg;  // packed image
-    int spt;           // k-steps per tap
-    int tiles_x, tiles_y;
-    const int* durations;  // [B] or null
-    int t;                 // current time step (compared with durations)
-    // LSTM epilogue
-    const float* bias;     // [4F] reference order
-    const float* c_prev;   // [B,H,W,F]
-    float* c_out;          // [B,H,W,F]
-    void* h_out;           // [B,H,W,F]
-    void* out;             // masked output or null; sample stride out_bstride elements
-    long long out_bstride;
-    void* gates;           // [B,H,W,F,4] (g,i,f,o) or null
-    // dgrad epilogue
-    void* dx;              // [B,H,W,dx_cstride] or null
-    int dx_channels, dx_cstride, dx_accumulate;
-    void* dh_prev;         // [B,H,W,F]; left untouched for a masked sample (state gradient passes through)
-    int row_split;         // rows [0, row_split) -> dx, [row_split, row_split + F) -> dh_prev
-};
 
 template <typename T>
 __device__ __forceinline__ void stage_tile(const void* in0, const void* in1, int c0, int c1, int H, int W, int b,
@@ -190,7 +108,7 @@ __device__ __forceinline__ void stage_tile(const void* in0, const void* in1, int
 // acc[t][pt] += sum over 9 taps and all channel groups.  Wave handles tile rows 2*wave, 2*wave+1.
 template <typename T, int MT>
 __device__ __forceinline__ void conv_mainloop(const char* lds_in, int pstride, const char* lds_w, const T* gw, int spt,
-                                              f32x16 (&acc)[MT][2]) {
+                                              int a_ss, int a_ts, f32x16 (&acc)[MT][2]) {
     using frag = typename Tr<T>::frag;
     constexpr int KG = Tr<T>::KG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -206,9 +124,9 @@ __device__ __forceinline__ void conv_mainloop(const char* lds_in, int pstride, c
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 if constexpr (Tr<T>::W_IN_LDS)
-                    a[t] = *reinterpret_cast<const frag*>(lds_w + ((size_t)(s * MT + t) * 64 + lane) * sizeof(frag));
+                    a[t] = *reinterpret_cast<const frag*>(lds_w + ((size_t)(s * a_ss + t * a_ts) * 64 + lane) * sizeof(frag));
                 else
-                    a[t] = *reinterpret_cast<const frag*>(gw + ((size_t)(s * MT + t) * 64 + lane) * KG);
+                    a[t] = *reinterpret_cast<const frag*>(gw + ((size_t)(s * a_ss + t * a_ts) * 64 + lane) * KG);
             }
             const frag b0 = *reinterpret_cast<const frag*>(b_tap + q * 2 * KG * (int)sizeof(T));
             const frag b1 = *reinterpret_cast<const frag*>(b_tap + HALO_W * pstride + q * 2 * KG * (int)sizeof(T));
@@ -218,26 +136,6 @@ __device__ __forceinline__ void conv_mainloop(const char* lds_in, int pstride, c
                 acc[t][1] = Tr<T>::mma(a[t], b1, acc[t][1]);
             }
         }
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void store4(T* dst, const float (&v)[4]) {
-    if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-    } else {
-        bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(dst) = o;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void load4(const T* src, float (&v)[4]) {
-    if constexpr (sizeof(T) == 4) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(src);
-        v[0] = x[0], v[1] = x[1], v[2] = x[2], v[3] = x[3];
-    } else {
-        const bf16x4 x = *reinterpret_cast<const bf16x4*>(src);
-        v[0] = (float)x[0], v[1] = (float)x[1], v[2] = (float)x[2], v[3] = (float)x[3];
     }
 }
 
@@ -271,42 +169,9 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(ConvParams p) {
         const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
         const bool live = p.durations == nullptr || p.t < p.durations[b];
 
-        if (!live) {
-            // dynamic_rnn past the sequence end: state copied through, emitted output zero
-            if (MODE == 0) {
-                for (int i = threadIdx.x; i < TH * TW * (F_ / 4); i += kThreads) {
-                    const int q4 = i & 3, pix = i >> 2;
-                    const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
-                    if (gy < p.H && gx < p.W) {
-                        const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
-                        const size_t o = pixel * F_ + q4 * 4;
-                        *reinterpret_cast<f32x4*>(p.c_out + o) = *reinterpret_cast<const f32x4*>(p.c_prev + o);
-                        float hv[4];
-                        load4(static_cast<const T*>(p.in1) + o, hv);
-                        store4(static_cast<T*>(p.h_out) + o, hv);
-                        if (p.out) {
-                            const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                            const size_t oo = (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + q4 * 4;
-                            store4(static_cast<T*>(p.out) + oo, z);
-                        }
-                    }
-                }
-                continue;  // (block-uniform branch: no barrier is skipped by part of the block)
-            }
-            // MODE 1: dY of a masked sample is all zero, so the convolution adds nothing and
-            // dh_prev keeps the incoming state gradient; only dx needs defining when not accumulating.
-            if (p.dx && !p.dx_accumulate) {
-                for (int i = threadIdx.x; i < TH * TW * (p.dx_channels / 4); i += kThreads) {
-                    const int nq = p.dx_channels / 4;
-                    const int q4 = i % nq, pix = i / nq;
-                    const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
-                    if (gy < p.H && gx < p.W) {
-                        const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
-                        const float z[4] = {0.f, 0.f, 0.f, 0.f};
-                        store4(static_cast<T*>(p.dx) + pixel * p.dx_cstride + q4 * 4, z);
-                    }
-                }
-            }
+        if (!live) {  // block-uniform branch: no barrier below is skipped by part of the block
+            if (MODE == 0) lstm_copy_through_tile<T>(p, b, ty0, tx0, threadIdx.x, kThreads);
+            else dgrad_zero_dx_tile<T>(p, b, ty0, tx0, threadIdx.x, kThreads);
             continue;
         }
 
@@ -321,79 +186,32 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(ConvParams p) {
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
-        conv_mainloop<T, MT>(lds_in, pstride, lds_w, static_cast<const T*>(p.wimg), p.spt, acc);
+        conv_mainloop<T, MT>(lds_in, pstride, lds_w, static_cast<const T*>(p.wimg), p.spt, p.a_sstride, p.a_tstride, acc);
 
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
             if (gy >= p.H || gx >= p.W) continue;
-            const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
             if constexpr (MODE == 0) {
                 static_assert(MODE != 0 || MT == 2, "forward image has 64 rows");
-                const size_t so = pixel * F_ + 8 * half;
-                float cp[8];
-                {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.c_prev + so);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.c_prev + so + 4);
-                    cp[0] = c0[0], cp[1] = c0[1], cp[2] = c0[2], cp[3] = c0[3];
-                    cp[4] = c1[0], cp[5] = c1[1], cp[6] = c1[2], cp[7] = c1[3];
-                }
-                float hn[8], cn[8], gs[32];
+                float z[32];
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int cl = 4 * t + a, ch = 8 * half + cl;
-                        const float g = tanh_t<T>(acc[t][pt][4 * a + 0] + lds_bias[ch]);
-                        const float ig = sigmoid_t<T>(acc[t][pt][4 * a + 1] + lds_bias[F_ + ch]);
-                        const float fg = sigmoid_t<T>(acc[t][pt][4 * a + 2] + lds_bias[2 * F_ + ch]);
-                        const float og = sigmoid_t<T>(acc[t][pt][4 * a + 3] + lds_bias[3 * F_ + ch]);
-                        const float c = fg * cp[cl] + ig * g;
-                        cn[cl] = c;
-                        hn[cl] = og * tanh_t<T>(c);
-                        gs[4 * cl + 0] = g, gs[4 * cl + 1] = ig, gs[4 * cl + 2] = fg, gs[4 * cl + 3] = og;
-                    }
-                *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
-                *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
-                {
-                    const float h0[4] = {hn[0], hn[1], hn[2], hn[3]}, h1[4] = {hn[4], hn[5], hn[6], hn[7]};
-                    store4(static_cast<T*>(p.h_out) + so, h0);
-                    store4(static_cast<T*>(p.h_out) + so + 4, h1);
-                    if (p.out) {
-                        const size_t oo = (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half;
-                        store4(static_cast<T*>(p.out) + oo, h0);
-                        store4(static_cast<T*>(p.out) + oo + 4, h1);
-                    }
-                }
-                if (p.gates) {
-                    T* gd = static_cast<T*>(p.gates) + pixel * NG + 32 * half;
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float v[4] = {gs[4 * k], gs[4 * k + 1], gs[4 * k + 2], gs[4 * k + 3]};
-                        store4(gd + 4 * k, v);
-                    }
-                }
+                        for (int g = 0; g < 4; ++g)
+                            z[4 * (4 * t + a) + g] = acc[t][pt][4 * a + g] + lds_bias[g * F_ + 8 * half + 4 * t + a];
+                lstm_finish_pixel<T, false>(p, b, gy, gx, half, z, p.hist_table);
             } else {
+                const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        const int cc0 = 32 * t + 8 * a + 4 * half;
                         float v[4] = {acc[t][pt][4 * a], acc[t][pt][4 * a + 1], acc[t][pt][4 * a + 2],
                                       acc[t][pt][4 * a + 3]};
-                        if (cc0 < p.row_split) {  // x part of the concatenated input
-                            if (p.dx && cc0 < p.dx_channels) {
-                                T* d = static_cast<T*>(p.dx) + pixel * p.dx_cstride + cc0;
-                                if (p.dx_accumulate) {
-                                    float old[4];
-                                    load4(d, old);
-                                    v[0] += old[0], v[1] += old[1], v[2] += old[2], v[3] += old[3];
-                                }
-                                store4(d, v);
-                            }
-                        } else if (cc0 < p.row_split + F_) {
-                            store4(static_cast<T*>(p.dh_prev) + pixel * F_ + (cc0 - p.row_split), v);
-                        }
+                        dgrad_store4<T>(p, pixel, p.row_base + 32 * t + 8 * a + 4 * half, v);
                     }
             }
         }
@@ -475,17 +293,6 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams
 // ---------------------------------------------------------------------------------------------
 // weight gradient:  slab[tap][cc][col] = sum_pixels XH[pixel + tap][cc] * dY[pixel][col]
 // ---------------------------------------------------------------------------------------------
-struct WgradParams {
-    const void* in0;  // x [B,H,W,c0]
-    const void* in1;  // h_prev [B,H,W,F]
-    int c0, c1;
-    const void* dy;   // [B,H,W,64] (channel, gate) order
-    int B, H, W, tiles_x, tiles_y;
-    const int* durations;
-    int t;
-    float* slab;       // [gridDim.x][9][MT*32][64]
-    float* bias_slab;  // [gridDim.x][64]
-};
 
 template <typename T, int MT>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
@@ -629,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
 
 // dw_x[tap][c][gate*F+ch] (+)= sum_blocks slab[blk][tap][c][ch*4+gate], same for dw_h and dbias.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nblk,
-                                    int MT, int C, int Cs, int accumulate, float* __restrict__ dw_x,
+                                    int MT, int C, int Cw, int Cs, int accumulate, float* __restrict__ dw_x,
                                     float* __restrict__ dw_h, float* __restrict__ dbias) {
     const int n_x = 9 * C * NG, n_h = 9 * F_ * NG;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,7 +451,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float*
             const int rem = idx - tap * C * NG;
             c = rem / NG;
             col = rem - c * NG;
-            dst = dw_x + idx;
+            dst = dw_x + ((size_t)tap * Cw + c) * NG + col;
         } else {
             const int j = idx - n_x;
             tap = j / (F_ * NG);
@@ -663,6 +470,38 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float*
         dst = dbias + col;
     }
     if (dst) *dst = accumulate ? *dst + sum : sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-hot history channels: weight-tap table (forward) and their weight gradient (backward)
+// ---------------------------------------------------------------------------------------------
+// table[tap][i][ch][gate] = w_x[tap][C + i][gate * F + ch]
+__global__ void hist_table_kernel(const float* __restrict__ w_x, int C, int hist, float* __restrict__ table) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 9 * hist * NG) return;
+    const int k = idx % NG, i = (idx / NG) % hist, tap = idx / (NG * hist);
+    const int ch = k >> 2, gate = k & 3;
+    table[idx] = w_x[((size_t)tap * (C + hist) + C + i) * NG + gate * F_ + ch];
+}
+
+// dw_x[tap][C + i][:] (+)= sum over live samples of dY at the one pixel that tap reaches from the point
+template <typename T>
+__global__ void hist_wgrad_kernel(const T* __restrict__ dy, const int* __restrict__ pts, long long pts_bstride,
+                                  int hist, int B, int H, int W, int C, const int* __restrict__ durations, int t,
+                                  int accumulate, float* __restrict__ dw_x) {
+    const int tap = blockIdx.x / hist, i = blockIdx.x - tap * hist;
+    const int k = threadIdx.x;  // dY channel, (channel, gate) order
+    const int ty = tap / 3, tx = tap - ty * 3;
+    float sum = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        if (durations != nullptr && t >= durations[b]) continue;
+        const int px = pts[(size_t)b * pts_bstride + 2 * i], py = pts[(size_t)b * pts_bstride + 2 * i + 1];
+        const int gy = py - ty + 1, gx = px - tx + 1;
+        if (px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            sum += (float)dy[(((size_t)b * H + gy) * W + gx) * NG + k];
+    }
+    float* dst = dw_x + ((size_t)tap * (C + hist) + C + i) * NG + (k & 3) * F_ + (k >> 2);
+    *dst = accumulate ? *dst + sum : sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -729,10 +568,11 @@ extern "C" long long isg_convlstm_packed_elems(int Cs, int F, int kind) {
     return (long long)9 * NG * MT * 32;  // dgrad image: MT*32 rows x (9 * 64)
 }
 
-extern "C" int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int F, int dtype,
-                                         void* packed_fwd, void* packed_dgrad, void* stream) {
+extern "C" int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int hist, int F, int dtype,
+                                         void* packed_fwd, void* packed_dgrad, float* hist_table, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
-    ISG_REQUIRE(w_x && w_h && C >= 1 && C <= Cs, ISG_EINVAL, "isg_convlstm_pack_weights: bad arguments");
+    ISG_REQUIRE(w_x && w_h && C >= 1 && C <= Cs && hist >= 0 && (hist == 0 || hist_table), ISG_EINVAL,
+                "isg_convlstm_pack_weights: bad arguments");
     int rc = check_channels("isg_convlstm_pack_weights", Cs, dtype);
     if (rc != ISG_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -745,41 +585,53 @@ extern "C" int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int
         const int mt = kind == 0 ? 2 : MT;
         const int blocks = (int)((total + 255) / 256);
         if (dtype == ISG_F32)
-            hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, Cs, kind, mt,
-                               static_cast<float*>(out), total);
+            hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, C + hist, Cs, kind,
+                               mt, static_cast<float*>(out), total);
         else
-            hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, Cs, kind, mt,
-                               static_cast<__bf16*>(out), total);
+            hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, w_x, w_h, C, C + hist, Cs,
+                               kind, mt, static_cast<__bf16*>(out), total);
         rc = isg::check_launch("pack_weights_kernel");
         if (rc != ISG_OK) return rc;
     }
-    return ISG_OK;
+    if (hist > 0) {
+        hipLaunchKernelGGL(hist_table_kernel, dim3((9 * hist * NG + 255) / 256), dim3(256), 0, s, w_x, C, hist,
+                           hist_table);
+        rc = isg::check_launch("hist_table_kernel");
+    }
+    return rc;
 }
 
 extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
                                      const float* bias, int B, int H, int W, int Cs, int F, int dtype,
-                                     const int32_t* durations, int t, void* h_out, float* c_out, void* out,
-                                     long long out_batch_stride, void* gates, void* stream) {
+                                     const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                                     long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
+                                     void* out, long long out_batch_stride, void* gates, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(x && h_prev && c_prev && packed_fwd && bias && h_out && c_out, ISG_EINVAL,
                 "isg_convlstm_cell_fwd: null pointer");
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_cell_fwd: bad shape");
+    ISG_REQUIRE(hist >= 0 && (hist == 0 || (hist_points && hist_table)), ISG_EINVAL,
+                "isg_convlstm_cell_fwd: history points and table are needed when hist > 0");
     int rc = check_channels("isg_convlstm_cell_fwd", Cs, dtype);
     if (rc != ISG_OK) return rc;
     ConvParams p = {};
     p.in0 = x, p.in1 = h_prev, p.c0 = Cs, p.c1 = F_;
     p.B = B, p.H = H, p.W = W;
     p.wimg = packed_fwd;
+    p.a_sstride = 2, p.a_tstride = 1;
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
     p.durations = durations, p.t = t;
     p.bias = bias, p.c_prev = c_prev, p.c_out = c_out, p.h_out = h_out, p.out = out;
     p.out_bstride = out_batch_stride, p.gates = gates;
+    p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_table = hist_table;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32) {
         p.spt = (Cs + F_) / 2;
         return launch_conv<float, 2, 0>(p, s);
     }
     p.spt = (Cs + F_) / 16;
+    rc = launch_conv_pp(p, 2, 0, num_cus(), s);
+    if (rc != kNotSupported) return rc;
     return launch_conv<__bf16, 2, 0>(p, s);
 }
 
@@ -826,9 +678,24 @@ extern "C" int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int 
     p.dx = dx, p.dx_channels = dx ? dx_channels : 0, p.dx_cstride = dx_channel_stride, p.dx_accumulate = dx_accumulate;
     p.dh_prev = dh_prev;
     p.row_split = Cs;
+    p.row_base = 0;
     p.spt = dtype == ISG_F32 ? NG / 2 : NG / 16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = (Cs + F_ + 31) / 32;
+    p.a_sstride = 1, p.a_tstride = 9 * p.spt;  // row-tile-major image
+    if (dtype == ISG_BF16) {
+        // fast path: one ping-pong launch per 32-row tile of the image (each re-stages dY from L2)
+        bool fast = true;
+        for (int tile = 0; tile < MT && fast; ++tile) {
+            ConvParams q = p;
+            q.wimg = static_cast<const char*>(packed_dgrad) + (size_t)tile * 9 * p.spt * 1024;
+            q.row_base = 32 * tile;
+            rc = launch_conv_pp(q, 1, 1, num_cus(), s);
+            if (rc == kNotSupported) fast = false;
+            else if (rc != ISG_OK) return rc;
+        }
+        if (fast) return ISG_OK;
+    }
     if (dtype == ISG_F32) {
         if (MT == 1) return launch_conv<float, 1, 1>(p, s);
         if (MT == 2) return launch_conv<float, 2, 1>(p, s);
@@ -848,7 +715,8 @@ extern "C" long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F) {
 }
 
 extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C,
-                                  int Cs, int F, int dtype, const int32_t* durations, int t, void* workspace,
+                                  int Cs, int F, int dtype, const int32_t* durations, int t,
+                                  const int32_t* hist_points, int hist, long long hist_batch_stride, void* workspace,
                                   int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(x && h_prev && dy && workspace && dw_x && dw_h && dbias, ISG_EINVAL,
@@ -870,7 +738,16 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t esz = dtype == ISG_F32 ? 4 : 2, pad = dtype == ISG_F32 ? 4 : 16;
     const size_t lds = (((size_t)NPX * ((Cs + F_) * esz + pad) + 15) & ~(size_t)15) + (size_t)TH * TW * (NG * esz + pad);
-    if (dtype == ISG_F32) {
+    bool launched = false;
+    if (dtype == ISG_BF16) {
+        rc = launch_wgrad_pp(p, MT, grid, s);
+        if (rc != kNotSupported) {
+            if (rc != ISG_OK) return rc;
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if (dtype == ISG_F32) {
         if (MT == 1) {
             if ((rc = set_lds(&conv_wgrad_kernel<float, 1>, lds)) != ISG_OK) return rc;
             hipLaunchKernelGGL((conv_wgrad_kernel<float, 1>), dim3(grid), dim3(kThreads), lds, s, p);
@@ -890,6 +767,18 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
     if ((rc = isg::check_launch("conv_wgrad_kernel")) != ISG_OK) return rc;
     const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, p.bias_slab, grid, MT,
-                       C, Cs, accumulate, dw_x, dw_h, dbias);
-    return isg::check_launch("wgrad_reduce_kernel");
+                       C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
+    if ((rc = isg::check_launch("wgrad_reduce_kernel")) != ISG_OK) return rc;
+    if (hist > 0) {
+        ISG_REQUIRE(hist_points, ISG_EINVAL, "isg_convlstm_wgrad: history points are needed when hist > 0");
+        if (dtype == ISG_F32)
+            hipLaunchKernelGGL(hist_wgrad_kernel<float>, dim3(9 * hist), dim3(NG), 0, s, static_cast<const float*>(dy),
+                               hist_points, hist_batch_stride, hist, B, H, W, C, durations, t, accumulate, dw_x);
+        else
+            hipLaunchKernelGGL(hist_wgrad_kernel<__bf16>, dim3(9 * hist), dim3(NG), 0, s,
+                               static_cast<const __bf16*>(dy), hist_points, hist_batch_stride, hist, B, H, W, C,
+                               durations, t, accumulate, dw_x);
+        rc = isg::check_launch("hist_wgrad_kernel");
+    }
+    return rc;
 }

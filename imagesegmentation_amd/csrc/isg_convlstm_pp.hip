@@ -1,0 +1,633 @@
+// bf16 fast path of the two convolution-shaped ConvLSTM kernels (forward gates + LSTM, data gradient).
+//
+// Why a second kernel: at 224 x 224 the cell is HBM-bound (about 380 B move per pixel-step against
+// 55 kFLOP), so what matters is keeping loads in flight while the matrix pipe and the VALU both work.
+// One 512-thread workgroup per CU holds the weight image in LDS once and runs TWO groups of 4 waves
+// in ping-pong on separate input buffers: while group A issues its 9 x SPT k-steps of MFMA on tile
+// a_i, group B runs the epilogue of b_(i-1) (gate math, stores) and stages b_i; a workgroup barrier
+// flips the roles.  Every SIMD hosts one wave of each group, so MFMA of one overlaps VALU/VMEM of the
+// other.  Staging is split: the global loads of the next tile are issued BEFORE the epilogue and
+// their LDS writes come after it, which keeps ~40 KB per CU in flight during the gate math.
+// The k-loop is fully unrolled with the next step's fragments read while the current MFMAs issue.
+#include "isg_convlstm_shared.h"
+
+using namespace isgc;
+
+namespace {
+
+constexpr int kPPThreads = 512;
+
+// Diagnostic build only (-DISG_STAMPS, see tools/stamp_conv.py): per-phase cycle sums of wave 0 of each
+// group, written to a buffer that nothing else reads.  In the shipped library no stamp executes.
+#ifdef ISG_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp()
+#define STAMP_ADD(slot, a, b) stamp_sum[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
+struct TileRef {
+    int b, ty0, tx0;
+    bool valid, live;  // live is known once the tile's staged words have landed (stage_store)
+    int hp[4];         // history points (x0, y0, x1, y1) of the tile's sample, same
+};
+
+// Read-only, wave-uniform words (sequence lengths, history points) go through the scalar cache: a
+// vector load here would also make the next s_waitcnt drain every store still in flight.
+__device__ __forceinline__ int scalar_load(const int* base, long long index) {
+    const long long i = (long long)__builtin_amdgcn_readfirstlane((int)index);
+    return *reinterpret_cast<const __attribute__((address_space(4))) int*>(
+        (const __attribute__((address_space(4))) char*)(unsigned long long)(base) + i * 4);
+}
+
+template <int C0, int C1, int MT, int MODE>
+struct PP {
+    static constexpr int CPT = C0 + C1;          // staged channels per pixel
+    static constexpr int NCH0 = C0 / 8;          // 16-byte chunks of in0 per pixel
+    static constexpr int NCH = CPT / 8;
+    static constexpr int SPT = CPT / 16;         // k-steps per tap
+    static constexpr int NS = 9 * SPT;
+    static constexpr int PSTRIDE = CPT * 2 + 16;  // LDS bytes per staged pixel (pad spreads banks)
+    static constexpr int IN_BYTES = (NPX * PSTRIDE + 15) & ~15;
+    static constexpr int W_BYTES = NS * MT * 1024;
+    static constexpr int NLOAD = (NPX * NCH + 255) / 256;  // staged chunks per thread per tile
+    static constexpr int TAB_FLOATS = NG + 9 * 2 * NG;     // bias + history taps (hist <= 2)
+    static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + (MODE == 0 ? TAB_FLOATS * 4 : 0);
+};
+
+// EARLY: request the tile after next already in the finish phase (two phases of flight, ahead of the
+// phase's stores) instead of at the start of the compute phase (one phase of flight).  Measured at
+// 224 x 224: better for the 48-channel forward cell, worse for the others.
+template <int C0, int C1, int MT, int MODE, bool EARLY>
+__global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
+    using K = PP<C0, C1, MT, MODE>;
+    using T = __bf16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);  // wave-uniform: 0 = group A, 1 = group B
+    const int gtid = tid & 255, lane = tid & 63, wave = gtid >> 6;
+    const int px_l = lane & 31, half = lane >> 5;
+    char* lds_w = smem;
+    char* lds_in = smem + K::W_BYTES + grp * K::IN_BYTES;
+    float* lds_tab = reinterpret_cast<float*>(smem + K::W_BYTES + 2 * K::IN_BYTES);
+
+    {  // weight image and tables, once per workgroup
+        const uint4* src = static_cast<const uint4*>(p.wimg);
+        uint4* dst = reinterpret_cast<uint4*>(lds_w);
+        for (int i = tid; i < K::W_BYTES / 16; i += kPPThreads) dst[i] = src[i];
+        if constexpr (MODE == 0) {
+            if (tid < NG) lds_tab[tid] = p.bias[(tid & 3) * F_ + (tid >> 2)];  // [channel][gate] order
+            for (int i = tid; i < 9 * p.hist * NG; i += kPPThreads) lds_tab[NG + i] = p.hist_table[i];
+        }
+    }
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    const int stride = 2 * gridDim.x;
+    const int n_iter = (ntiles + stride - 1) / stride;
+
+    auto tile_ref = [&](int k) {
+        TileRef r;
+        const int tile = k * stride + 2 * blockIdx.x + grp;
+        r.valid = k < n_iter && tile < ntiles;
+        r.b = 0, r.ty0 = 0, r.tx0 = 0, r.live = false;
+        r.hp[0] = r.hp[2] = -1, r.hp[1] = r.hp[3] = 0;
+        if (r.valid) {
+            r.b = tile / tiles_per_img;
+            const int rem = tile - r.b * tiles_per_img;
+            const int tyi = rem / p.tiles_x;
+            r.ty0 = tyi * TH, r.tx0 = (rem - tyi * p.tiles_x) * TW;
+        }
+        return r;
+    };
+
+    // Staging is split in two: the loads are issued unconditionally from clamped (always valid)
+    // addresses so that nothing has to look at the data until the LDS write one phase later, where
+    // chunks that lie outside the image are replaced by zeros (the SAME padding).
+    // The sample's sequence length and history points ride along with the staged data as ordinary
+    // vector loads (same wave-uniform address in every lane): they are consumed phases later through
+    // readfirstlane, so neither a scalar-cache round trip nor a drained store queue is ever waited for.
+    uint4 st[K::NLOAD];
+    int st_meta[5] = {0x7fffffff, -1, 0, -1, 0};
+    unsigned st_inside = 0u;  // bit j: chunk j of this thread lies inside the image
+    auto stage_load = [&](const TileRef& r) {
+        if (!r.valid) return;
+        st_inside = 0u;
+        st_meta[0] = 0x7fffffff;
+        if (p.durations != nullptr) st_meta[0] = p.durations[r.b];
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < 2 * p.hist) st_meta[1 + i] = p.hist_points[(size_t)r.b * p.hist_bstride + i];
+        }
+        int g = gtid;
+        asm volatile("" : "+v"(g));  // recompute the per-chunk coordinates each time: cheaper than keeping
+                                     // 2 * NLOAD loop-invariant registers alive across the k-loop
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = min(g + 256 * j, NPX * K::NCH - 1);
+            const int px = idx / K::NCH, ch = idx - px * K::NCH;
+            const int hy = px / HALO_W, hx = px - hy * HALO_W;
+            const int gy = r.ty0 + hy - 1, gx = r.tx0 + hx - 1;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) st_inside |= 1u << j;
+            const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+            const size_t pixel = ((size_t)r.b * p.H + cy) * p.W + cx;
+            const T* src = ch < K::NCH0 ? static_cast<const T*>(p.in0) + pixel * C0 + ch * 8
+                                        : static_cast<const T*>(p.in1) + pixel * C1 + (ch - K::NCH0) * 8;
+            st[j] = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    auto stage_store = [&](TileRef& r) {
+        if (!r.valid) return;
+        r.live = p.t < __builtin_amdgcn_readfirstlane(st_meta[0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.hp[i] = __builtin_amdgcn_readfirstlane(st_meta[1 + i]);
+        if (!r.live) return;
+        int g = gtid;
+        asm volatile("" : "+v"(g));
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = g + 256 * j;
+            const int px = idx / K::NCH, ch = idx - px * K::NCH;
+            const bool in = (st_inside >> j) & 1u;
+            const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NPX * K::NCH) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = v;
+        }
+    };
+
+    f32x16 acc[MT][2];
+    auto mainloop = [&]() {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
+        const char* bb = lds_in + ((2 * wave) * HALO_W + px_l) * K::PSTRIDE + half * 16;
+        const char* aw = lds_w + lane * 16;
+        bf16x8 a[2][MT], bf[2][2];
+        auto fetch = [&](int s, int slot) {
+            const int tap = s / K::SPT, q = s - tap * K::SPT;
+            const int off = ((tap / 3) * HALO_W + (tap % 3)) * K::PSTRIDE + q * 32;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(aw + (s * MT + t) * 1024);
+            bf[slot][0] = *reinterpret_cast<const bf16x8*>(bb + off);
+            bf[slot][1] = *reinterpret_cast<const bf16x8*>(bb + HALO_W * K::PSTRIDE + off);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < K::NS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < K::NS) fetch(s + 1, cur ^ 1);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t], bf[cur][0], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t], bf[cur][1], acc[t][1], 0, 0, 0);
+            }
+            // keep the prefetch distance at one k-step: without this fence the scheduler hoists many
+            // steps of LDS reads ahead and the register file overflows into scratch
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Operands the epilogue needs from global memory (previous cell state, or the running dx sum when
+    // accumulating) are requested at the START of the compute phase and consumed one phase later, so
+    // no load latency is exposed between the MFMAs and the stores.
+    constexpr int NPRE = MODE == 0 ? 4 : 2 * MT * 4;
+    uint4 pre[NPRE];
+    auto prefetch_epilogue = [&](const TileRef& r) {
+        if (!(r.valid && r.live)) return;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int gy = min(r.ty0 + 2 * wave + pt, p.H - 1), gx = min(r.tx0 + px_l, p.W - 1);
+            const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
+            if constexpr (MODE == 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half);
+                pre[2 * pt] = src[0];
+                pre[2 * pt + 1] = src[1];
+            } else {
+                if (p.dx && p.dx_accumulate) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int a4 = 0; a4 < 4; ++a4) {
+                            const int cc0 = p.row_base + 32 * t + 8 * a4 + 4 * half;
+                            uint2 v = make_uint2(0u, 0u);
+                            if (cc0 < p.row_split && cc0 < p.dx_channels)
+                                v = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.dx) + pixel * p.dx_cstride + cc0);
+                            pre[(pt * MT + t) * 4 + a4] = make_uint4(v.x, v.y, 0u, 0u);
+                        }
+                }
+            }
+        }
+    };
+
+    auto epilogue = [&](const TileRef& r) {
+        if (!r.valid) return;
+        if (!r.live) {
+            if constexpr (MODE == 0) lstm_copy_through_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256);
+            else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256);
+            return;
+        }
+        const int hpx[2] = {p.hist > 0 ? r.hp[0] : -1, p.hist > 1 ? r.hp[2] : -1};
+        const int hpy[2] = {r.hp[1], r.hp[3]};
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int gy = r.ty0 + 2 * wave + pt, gx = r.tx0 + px_l;
+            if (gy >= p.H || gx >= p.W) continue;
+            if constexpr (MODE == 0) {
+                // one channel at a time: 4 accumulator registers + bias (+ history taps) -> gates ->
+                // state; gate activations leave as 16-byte stores every second channel
+                const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
+                const size_t so = pixel * F_ + 8 * half;
+                const float cp[8] = {__uint_as_float(pre[2 * pt].x),     __uint_as_float(pre[2 * pt].y),
+                                     __uint_as_float(pre[2 * pt].z),     __uint_as_float(pre[2 * pt].w),
+                                     __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
+                                     __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
+                int tap_off[2] = {-1, -1};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ty = hpy[i] - gy + 1, tx = hpx[i] - gx + 1;
+                    if (hpx[i] >= 0 && (unsigned)ty < 3u && (unsigned)tx < 3u)
+                        tap_off[i] = NG + ((ty * 3 + tx) * p.hist + i) * NG + 32 * half;
+                }
+                T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
+                float hn[8], cn[8], gprev[4];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int a4 = 0; a4 < 4; ++a4) {
+                        const int cl = 4 * t + a4;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_tab + 32 * half + 4 * cl);
+                        float z[4] = {acc[t][pt][4 * a4] + b4[0], acc[t][pt][4 * a4 + 1] + b4[1],
+                                      acc[t][pt][4 * a4 + 2] + b4[2], acc[t][pt][4 * a4 + 3] + b4[3]};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (tap_off[i] >= 0) {
+                                const f32x4 tb = *reinterpret_cast<const f32x4*>(lds_tab + tap_off[i] + 4 * cl);
+                                z[0] += tb[0], z[1] += tb[1], z[2] += tb[2], z[3] += tb[3];
+                            }
+                        const float g = act_tanh<true>(z[0]), ig = act_sigmoid<true>(z[1]);
+                        const float fg = act_sigmoid<true>(z[2]), og = act_sigmoid<true>(z[3]);
+                        const float c = fg * cp[cl] + ig * g;
+                        cn[cl] = c;
+                        hn[cl] = og * act_tanh<true>(c);
+                        if (cl & 1) {
+                            if (gd) {
+                                const float pair[8] = {gprev[0], gprev[1], gprev[2], gprev[3], g, ig, fg, og};
+                                store8(gd + 4 * (cl - 1), pair);
+                            }
+                        } else {
+                            gprev[0] = g, gprev[1] = ig, gprev[2] = fg, gprev[3] = og;
+                        }
+                    }
+                *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+                *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
+                store8(static_cast<T*>(p.h_out) + so, hn);
+                if (p.out)
+                    store8(static_cast<T*>(p.out) + (size_t)r.b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
+            } else {
+                const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int a4 = 0; a4 < 4; ++a4) {
+                        float v[4] = {acc[t][pt][4 * a4], acc[t][pt][4 * a4 + 1], acc[t][pt][4 * a4 + 2],
+                                      acc[t][pt][4 * a4 + 3]};
+                        const int cc0 = p.row_base + 32 * t + 8 * a4 + 4 * half;
+                        if (p.dx && p.dx_accumulate && cc0 < p.row_split && cc0 < p.dx_channels) {
+                            const uint4 o = pre[(pt * MT + t) * 4 + a4];
+                            v[0] += __uint_as_float(o.x << 16), v[1] += __uint_as_float(o.x & 0xFFFF0000u);
+                            v[2] += __uint_as_float(o.y << 16), v[3] += __uint_as_float(o.y & 0xFFFF0000u);
+                            store4(static_cast<T*>(p.dx) + pixel * p.dx_cstride + cc0, v);
+                        } else {
+                            dgrad_store4<T>(p, pixel, cc0, v);
+                        }
+                    }
+            }
+        }
+    };
+
+    // Schedule.  Half-step h: a group computes when (h + grp) is even.  Entering a compute phase it
+    // first requests the NEXT tile's input and the CURRENT tile's epilogue operands, then runs the
+    // k-loop; in its other phase it finishes the tile (gate math, stores) and writes the staged
+    // registers into its LDS buffer.  Both groups meet at the barrier that ends each half-step.
+    //   h:   0                      1                           2              3
+    //   A:   compute a0             store a1; load a2; epi a0   compute a1     store a2; load a3; epi a1
+    //   B:   store b0; load b1      compute b0                  store b1; load b2; epi b0   compute b1
+#ifdef ISG_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TileRef cur = tile_ref(0);
+    TileRef pending = cur, done = cur;
+    bool have_acc = false;
+    int knext = 1;
+    stage_load(cur);
+    if (grp == 0) {
+        stage_store(cur);
+        if constexpr (EARLY) {
+            pending = tile_ref(knext++);
+            stage_load(pending);
+        }
+    }
+    __syncthreads();
+    const int n_half = 2 * n_iter + 2;
+    STAMP(t_begin);
+    for (int h = 0; h < n_half; ++h) {
+        STAMP(t0);
+        if (((h + grp) & 1) == 0) {
+            if constexpr (!EARLY) {
+                pending = tile_ref(knext++);
+                stage_load(pending);
+            }
+            prefetch_epilogue(cur);
+            STAMP(t1);
+            if (cur.valid && cur.live) mainloop();
+            STAMP(t2);
+            STAMP_ADD(0, t0, t1);  // issue of the prefetch loads
+            STAMP_ADD(1, t1, t2);  // k-loop
+            done = cur;
+            have_acc = true;
+        } else {
+            stage_store(pending);  // requested two phases ago
+            cur = pending;
+            // the tile after that: requested BEFORE this phase's stores are issued, so that the
+            // load destinations are never registers a store still has to read
+            if constexpr (EARLY) {
+                pending = tile_ref(knext++);
+                stage_load(pending);
+            }
+            STAMP(t1);
+            if (have_acc) epilogue(done);
+            have_acc = false;
+            STAMP(t2);
+            STAMP_ADD(2, t0, t1);  // wait for the staged loads + LDS writes
+            STAMP_ADD(3, t1, t2);  // epilogue
+        }
+        STAMP(t3);
+        __syncthreads();
+        STAMP(t4);
+        STAMP_ADD(4 + ((h + grp) & 1), t3, t4);  // barrier wait after a compute / a finish phase
+    }
+#ifdef ISG_STAMPS
+    STAMP(t_end);
+    stamp_sum[6] = t_end - t_begin;
+    stamp_sum[7] = n_half;
+    if (g_stamp_buf != nullptr && (tid & 255) == 0)
+        for (int k = 0; k < 8; ++k) g_stamp_buf[(blockIdx.x * 2 + grp) * 8 + k] = stamp_sum[k];
+#endif
+}
+
+template <int C0, int C1, int MT, int MODE, bool EARLY>
+int launch_pp(const ConvParams& p, int num_cus, hipStream_t stream) {
+    using K = PP<C0, C1, MT, MODE>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
+    if (MODE == 0 && p.hist > 2) return kNotSupported;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int pairs = (ntiles + 1) / 2;
+    const int grid = pairs < num_cus ? pairs : num_cus;
+    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream, p);
+    return isg::check_launch("conv3x3_pp_kernel");
+}
+
+}  // namespace
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient, bf16 fast path
+// ---------------------------------------------------------------------------------------------
+// slab[tap][cc][col] = sum over this workgroup's pixels of XH[pixel + tap][cc] * dY[pixel][col].
+// Eight waves share the 9 taps x MT row tiles x 2 column tiles of one 8 x 32-pixel tile; the tile's
+// [x | h_prev] halo image and its dY image sit in LDS pixel-major and both MFMA operands come out of
+// them through the transposing read (the reduction runs over pixels).  The next tile's images are
+// requested into registers before the k-loop and written to the other LDS buffer after it.
+template <int C0, int MT>
+struct WG {
+    static constexpr int CPT = C0 + F_;
+    static constexpr int NCH0 = C0 / 8, NCH = CPT / 8;
+    static constexpr int PSTRIDE = CPT * 2 + 16;
+    static constexpr int DSTRIDE = NG * 2 + 16;
+    static constexpr int IN_BYTES = (NPX * PSTRIDE + 15) & ~15;
+    static constexpr int DY_BYTES = TH * TW * DSTRIDE;
+    static constexpr int BUF_BYTES = IN_BYTES + DY_BYTES;
+    static constexpr int NCHUNK = NPX * NCH + TH * TW * 8;  // 16-byte chunks per tile (input halo + dY)
+    static constexpr int NLOAD = (NCHUNK + kPPThreads - 1) / kPPThreads;
+    static constexpr int NSLOT = MT == 2 ? 5 : 3;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
+
+template <int C0, int MT>
+__global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p) {
+    using K = WG<C0, MT>;
+    using T = __bf16;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    // which output tiles this wave owns
+    int mt, nt, tap0, ntaps;
+    if constexpr (MT == 2) {
+        mt = (wave >> 1) & 1, nt = wave & 1, tap0 = (wave >> 2) * 5, ntaps = (wave >> 2) ? 4 : 5;
+    } else {
+        const int q = wave >> 1;
+        mt = 0, nt = wave & 1, tap0 = q == 0 ? 0 : 2 * q + 1, ntaps = q == 0 ? 3 : 2;
+    }
+    const bool does_bias = wave < 2;
+
+    f32x16 acc[K::NSLOT];
+#pragma unroll
+    for (int i = 0; i < K::NSLOT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    const int n_iter = (ntiles + gridDim.x - 1) / gridDim.x;
+
+    uint4 st[K::NLOAD];
+    int st_dur = 0x7fffffff;
+    unsigned st_inside = 0u;
+    auto stage_load = [&](int k) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return;
+        const int b = tile / tiles_per_img;
+        const int rem = tile - b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+        st_dur = 0x7fffffff;
+        if (p.durations != nullptr) st_dur = p.durations[b];
+        st_inside = 0u;
+        int g = tid;
+        asm volatile("" : "+v"(g));
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = min(g + kPPThreads * j, K::NCHUNK - 1);
+            const T* src;
+            bool inside;
+            if (idx < NPX * K::NCH) {
+                const int px = idx / K::NCH, ch = idx - px * K::NCH;
+                const int hy = px / HALO_W, hx = px - hy * HALO_W;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+                const size_t pixel = ((size_t)b * p.H + cy) * p.W + cx;
+                src = ch < K::NCH0 ? static_cast<const T*>(p.in0) + pixel * C0 + ch * 8
+                                   : static_cast<const T*>(p.in1) + pixel * F_ + (ch - K::NCH0) * 8;
+            } else {
+                const int d = idx - NPX * K::NCH;
+                const int px = d >> 3, ch = d & 7;
+                const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
+                inside = gy < p.H && gx < p.W;
+                const int cy = min(gy, p.H - 1), cx = min(gx, p.W - 1);
+                src = static_cast<const T*>(p.dy) + (((size_t)b * p.H + cy) * p.W + cx) * NG + ch * 8;
+            }
+            if (inside) st_inside |= 1u << j;
+            st[j] = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    // returns whether the staged tile takes part (its sample is still running at step t)
+    auto stage_store = [&](int k, char* buf) -> bool {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return false;
+        const bool live = p.t < __builtin_amdgcn_readfirstlane(st_dur);
+        if (!live) return false;
+        int g = tid;
+        asm volatile("" : "+v"(g));
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = g + kPPThreads * j;
+            const bool in = (st_inside >> j) & 1u;
+            const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
+            if (idx < NPX * K::NCH) {
+                const int px = idx / K::NCH, ch = idx - px * K::NCH;
+                *reinterpret_cast<uint4*>(buf + px * K::PSTRIDE + ch * 16) = v;
+            } else if (idx < K::NCHUNK) {
+                const int d = idx - NPX * K::NCH;
+                *reinterpret_cast<uint4*>(buf + K::IN_BYTES + (d >> 3) * K::DSTRIDE + (d & 7) * 16) = v;
+            }
+        }
+        return true;
+    };
+
+    auto compute = [&](const char* buf) {
+        const char* lds_in = buf;
+        const char* lds_dy = buf + K::IN_BYTES;
+        const int li = lane & 15, g16 = lane >> 4;
+        const int q = li >> 2, pp4 = li & 3;
+        const int csub = 16 * (g16 & 1) + 4 * pp4;  // channel offset inside the 32-row tile
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int r = ks >> 1, x0 = (ks & 1) * 16;
+            const int pj = x0 + 8 * half + q;
+            bf16x8 bfrag;
+            {
+                const char* a0 = lds_dy + (r * TW + pj) * K::DSTRIDE + (32 * nt + csub) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::DSTRIDE));
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfrag = __builtin_bit_cast(bf16x8, both);
+            }
+            if (does_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)bfrag[j];
+            }
+#pragma unroll
+            for (int i = 0; i < K::NSLOT; ++i) {
+                if (i < ntaps) {
+                    const int tap = tap0 + i;
+                    const int dy = tap / 3, dx = tap - dy * 3;
+                    const char* a0 = lds_in + ((r + dy) * HALO_W + pj + dx) * K::PSTRIDE + (32 * mt + csub) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::PSTRIDE));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    stage_load(0);
+    bool live = stage_store(0, smem);
+    __syncthreads();
+    for (int k = 0; k < n_iter; ++k) {
+        stage_load(k + 1);
+        if (live) compute(smem + (k & 1) * K::BUF_BYTES);
+        live = stage_store(k + 1, smem + ((k + 1) & 1) * K::BUF_BYTES);
+        __syncthreads();
+    }
+
+    float* slab = p.slab + (size_t)blockIdx.x * 9 * (MT * 32) * NG;
+#pragma unroll
+    for (int i = 0; i < K::NSLOT; ++i) {
+        if (i < ntaps) {
+            const int tap = tap0 + i;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                slab[((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31)] = acc[i][reg];
+            }
+        }
+    }
+    if (does_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0) p.bias_slab[(size_t)blockIdx.x * NG + 32 * nt + lane] = bsum;
+    }
+}
+
+template <int C0, int MT>
+int launch_wg(const WgradParams& p, int grid, hipStream_t stream) {
+    using K = WG<C0, MT>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "weight-gradient LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<C0, MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((conv_wgrad_pp_kernel<C0, MT>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream, p);
+    return isg::check_launch("conv_wgrad_pp_kernel");
+}
+
+}  // namespace
+
+#ifdef ISG_STAMPS
+extern "C" int isg_debug_set_stamp_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+namespace isgc {
+
+int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream_t stream) {
+    if (mode == 0) {
+        if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, false>(p, num_cus, stream);
+        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, true>(p, num_cus, stream);
+        return kNotSupported;
+    }
+    if (p.c0 == NG && p.c1 == 0 && mt == 1) return launch_pp<NG, 0, 1, 1, false>(p, num_cus, stream);
+    return kNotSupported;
+}
+
+int launch_wgrad_pp(const WgradParams& p, int mt, int grid, hipStream_t stream) {
+    if (p.c1 != F_) return kNotSupported;
+    if (p.c0 == 16 && mt == 1) return launch_wg<16, 1>(p, grid, stream);
+    if (p.c0 == 32 && mt == 2) return launch_wg<32, 2>(p, grid, stream);
+    return kNotSupported;
+}
+
+}  // namespace isgc

@@ -37,9 +37,10 @@ class PackedWeights:
     """MFMA operand images of one cell's weights (forward + data-gradient), see
     isg_convlstm_pack_weights."""
 
-    def __init__(self, w_x, w_h, bias, cs, dtype):
+    def __init__(self, w_x, w_h, bias, cs, dtype, hist=0):
         _need_cuda(w_x, "w_x")
-        self.c = int(w_x.shape[2])
+        self.hist = int(hist)            # trailing one-hot input channels applied as a tap scatter
+        self.c = int(w_x.shape[2]) - self.hist  # channels that go through the GEMM
         self.cs = int(cs)
         self.f = int(w_h.shape[2])
         self.dtype = dtype
@@ -51,17 +52,31 @@ class PackedWeights:
         self.fwd = torch.empty([n_fwd], dtype=dtype, device=w_x.device)
         self.dgrad = torch.empty([n_dg], dtype=dtype, device=w_x.device)
         self.bias = bias.detach().to(torch.float32).contiguous()
+        self.hist_table = torch.empty([9, self.hist, self.f, 4], dtype=torch.float32, device=w_x.device) \
+            if self.hist else None
         w_x32 = w_x.detach().to(torch.float32).contiguous()
         w_h32 = w_h.detach().to(torch.float32).contiguous()
-        rc = lib.isg_convlstm_pack_weights(_lib.ptr(w_x32), _lib.ptr(w_h32), self.c, self.cs, self.f,
+        rc = lib.isg_convlstm_pack_weights(_lib.ptr(w_x32), _lib.ptr(w_h32), self.c, self.cs, self.hist, self.f,
                                            dtype_code(dtype), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
-                                           _lib.current_stream())
+                                           _lib.ptr(self.hist_table), _lib.current_stream())
         _lib.check(rc, "isg_convlstm_pack_weights")
 
 
+def _points_arg(hist_points, hist):
+    """(pointer, ints between samples) of an int32 [B, hist, 2] view whose last two axes are dense."""
+    if hist == 0:
+        return None, 0
+    if hist_points is None:
+        raise ValueError("these packed weights expect %d history point(s) per sample" % hist)
+    assert hist_points.dtype == torch.int32 and hist_points.shape[1:] == (hist, 2)
+    assert hist_points.stride(2) == 1 and hist_points.stride(1) == 2
+    return hist_points.data_ptr(), hist_points.stride(0)
+
+
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
-             h_out=None, c_out=None, gates=None):
+             h_out=None, c_out=None, gates=None, hist_points=None):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
+    hist_points: int32 [B,hist,2] when the packed weights carry history channels.
     Returns (h, c, gates)."""
     _need_cuda(x, "x")
     B, H, W, Cs = x.shape
@@ -72,9 +87,11 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
     if gates is None and save_gates:
         gates = torch.empty([B, H, W, F, 4], dtype=x.dtype, device=x.device)
+    pts, pts_stride = _points_arg(hist_points, packed.hist)
     rc = _lib.lib().isg_convlstm_cell_fwd(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd),
                                           _lib.ptr(packed.bias), B, H, W, Cs, F, dtype_code(x.dtype),
-                                          _lib.ptr(durations), int(t), _lib.ptr(h), _lib.ptr(c),
+                                          _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,
+                                          _lib.ptr(packed.hist_table), _lib.ptr(h), _lib.ptr(c),
                                           out.data_ptr() if out is not None else None, int(out_batch_stride),
                                           _lib.ptr(gates), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_cell_fwd")
@@ -121,13 +138,16 @@ def wgrad_workspace(cs, f, device):
     return ws
 
 
-def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0):
-    """Parameter gradients of one step into float32 dw_x [3,3,C,4F], dw_h [3,3,F,4F], dbias [4F]."""
+def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0, hist_points=None, hist=0):
+    """Parameter gradients of one step into float32 dw_x [3,3,C+hist,4F], dw_h [3,3,F,4F], dbias [4F];
+    c_real = channels of x that went through the GEMM."""
     B, H, W, Cs = x.shape
     F = h_prev.shape[-1]
     ws = wgrad_workspace(Cs, F, x.device)
+    pts, pts_stride = _points_arg(hist_points, hist)
     rc = _lib.lib().isg_convlstm_wgrad(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(dy), B, H, W, int(c_real), Cs, F,
-                                       dtype_code(x.dtype), _lib.ptr(durations), int(t), _lib.ptr(ws),
+                                       dtype_code(x.dtype), _lib.ptr(durations), int(t), pts, int(hist), pts_stride,
+                                       _lib.ptr(ws),
                                        int(bool(accumulate)), _lib.ptr(dw_x), _lib.ptr(dw_h), _lib.ptr(dbias),
                                        _lib.current_stream())
     _lib.check(rc, "isg_convlstm_wgrad")

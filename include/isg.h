@@ -95,19 +95,31 @@ int isg_history_frames(const int32_t* points, int n, int size, int hist, int dty
  * images the kernels read (call it again whenever the weights change).
  */
 
+/* One-hot history inputs.  The reference concatenates `hist` one-hot frames to x as extra channels
+ * (reference polyrnn/History2LargeExperiment.py:25).  A one-hot channel through a 3x3 convolution is a
+ * 9-tap weight scatter, so the kernels can take those channels as vertex points instead of dense
+ * frames: w_x then has C + hist input channels, of which the first C go through the GEMM (x holds
+ * only those) and the last `hist` are applied from `hist_table` around each frame's point.  Pass
+ * hist = 0 to treat every channel densely.
+ */
+
 /* Elements (of `dtype`) of a packed image: kind 0 = forward image, 1 = data-gradient image. */
 long long isg_convlstm_packed_elems(int Cs, int F, int kind);
 
-int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int F, int dtype,
-                              void* packed_fwd, void* packed_dgrad /* either may be NULL */, void* stream);
+/* w_x float [3][3][C + hist][4F].  hist_table: float [9][hist][F][4] out (NULL when hist == 0). */
+int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs, int hist, int F, int dtype,
+                              void* packed_fwd, void* packed_dgrad /* either may be NULL */, float* hist_table,
+                              void* stream);
 
 /* Forward step.  h_out/c_out: new state [B][H][W][F].  out (optional): the emitted output, written
  * at out + b*out_batch_stride + (y*W + x)*F so that it can land in a [B][T][H][W][F] tensor.
  * gates (optional): [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), kept for the
- * backward pass. */
+ * backward pass.  hist_points: int32 (x, y) pairs of this step's frames, sample b at
+ * hist_points + b*hist_batch_stride, x < 0 = empty frame. */
 int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
                           const float* bias, int B, int H, int W, int Cs, int F, int dtype,
-                          const int32_t* durations, int t, void* h_out, float* c_out, void* out,
+                          const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                          long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out, void* out,
                           long long out_batch_stride, void* gates, void* stream);
 
 /* Backward, step 1 (pointwise): from dL/dh (= dh_above as emitted output + dh_state as carried
@@ -127,13 +139,14 @@ int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int B, int H, i
                        const int32_t* durations, int t, void* dx, int dx_channels, int dx_channel_stride,
                        int dx_accumulate, void* dh_prev, void* stream);
 
-/* Backward, step 3 (parameter gradients): dw_x [3][3][C][4F], dw_h [3][3][F][4F], dbias [4F], all
- * float, overwritten or (accumulate != 0) added to.  workspace: device scratch of
+/* Backward, step 3 (parameter gradients): dw_x [3][3][C + hist][4F], dw_h [3][3][F][4F], dbias [4F],
+ * all float, overwritten or (accumulate != 0) added to.  workspace: device scratch of
  * isg_convlstm_wgrad_workspace_bytes(Cs, F) bytes; needs Cs + F <= 64. */
 long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F);
 int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C, int Cs, int F,
-                       int dtype, const int32_t* durations, int t, void* workspace, int accumulate, float* dw_x,
-                       float* dw_h, float* dbias, void* stream);
+                       int dtype, const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                       long long hist_batch_stride, void* workspace, int accumulate, float* dw_x, float* dw_h,
+                       float* dbias, void* stream);
 
 /* ---- vertex decoding over the class grid ----------------------------------------------------
  * logits: `dtype` [rows][cols] (cols = P*P or P*P + 1).  One wave per row.

@@ -90,15 +90,17 @@ def test_fp32_logits_loss_grads_and_adam_step(name, kw):
         assert np.abs(p.detach().double().cpu().numpy() - want).max() < 1e-2 * step + 1e-9
 
 
-def test_bf16_model_tracks_the_oracle():
+@pytest.mark.parametrize("name", ["History2Large", "RNNConv", "EndTokenDeep_2"])
+def test_bf16_model_tracks_the_oracle(name):
     """Documented bf16 tolerance: logits within 5e-2 of the largest logit magnitude; loss within 2e-2."""
     from imagesegmentation_amd.polyrnn import experiments
     P, B = 28, 4
     rs = np.random.RandomState(99)
-    model = experiments.make("History2Large", image_size=P, compute_dtype=torch.bfloat16, device="cuda:0")
-    params = make_params(rs, P, 2, encoder=model.encoder_spec, layers=2, units=model.num_classes)
+    model = experiments.make(name, image_size=P, compute_dtype=torch.bfloat16, device="cuda:0")
+    hist, T = model.history_length, model.max_timesteps
+    params = make_params(rs, P, hist, encoder=model.encoder_spec, layers=model.rnn_layers, units=model.num_classes)
     _load(model, params)
-    images, histories, durations, targets = make_batch(rs, B, 10, P, 2)
+    images, histories, durations, targets = make_batch(rs, B, T, P, hist, end_token=model.end_token)
     loss_ref, logits_ref, grads_ref = oc.model_loss_and_grads(params, images, histories, durations, targets, P)
     loss = model.train_step(images, durations, histories, targets)
     assert rel_err(model.prediction_logits.float(), logits_ref) < 5e-2
@@ -117,7 +119,8 @@ def test_points_and_dense_histories_agree_and_train_reduces_loss():
     with torch.no_grad():
         a, _ = model.forward(images, d, h)
         b, _ = model.forward(images2, d2, pts)
-    assert torch.equal(a, b)
+    # dense frames go through the GEMM, points through the tap scatter: same sum, different order
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
     model.learning_rate = 1e-3
     first = model.train_step(images, d, pts, t).item()
     for _ in range(30):
