@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--rollouts", type=int, default=16384, help="IoU rollouts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
 
 
@@ -84,7 +86,7 @@ def event_time_ms(fn, reps):
     return start.elapsed_time(end) / reps
 
 
-def time_kernels(model, batch, dtype_name):
+def time_kernels(model, batch, dtype_name, reps=5):
     """Average launch duration of each ConvLSTM kernel at the workload's two layer shapes, with HIP events
     on the stream the kernels are launched on (torch's current stream)."""
     from imagesegmentation_amd import ops
@@ -115,25 +117,43 @@ def time_kernels(model, batch, dtype_name):
         flops = 2.0 * B * P * P * 9 * (c_real + F) * 4 * F
         esz = 2 if dt == torch.bfloat16 else 4
         px = B * P * P
+        # algorithmic HBM bytes per pixel: every operand read once, every result written once
+        x_b, h_b, c_b, g_b = (cs if hist else c_real) * esz, F * esz, F * 4, 4 * F * esz
         kernels = [
             ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts), flops,
-             "mfma"),
+             px * (x_b + h_b + c_b + h_b + c_b + g_b)),
             ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
-             px * (2 * 4 * F * esz + 2 * F * esz + 4 * F * 4), "hbm"),
-            ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, "mfma"),
+             0.0, px * (2 * g_b + 2 * h_b + 4 * c_b)),
+            ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, px * (g_b + x_b + h_b)),
             ("wgrad", lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, accumulate=False, hist_points=pts, hist=hist),
-             flops, "mfma"),
+             flops, px * (x_b + h_b + g_b)),
         ]
-        for name, fn, work, bound in kernels:
-            ms = event_time_ms(fn, 5)
-            rec = {"kernel": "%s[layer%d C=%d]" % (name, l, c_real), "ms": ms, "bound": bound}
-            if bound == "mfma":
-                rec.update(achieved=work / ms / 1e9, peak=MFMA_PEAK_TFLOPS[dtype_name], unit="TFLOP/s")
+        for name, fn, work, nbytes in kernels:
+            ms = event_time_ms(fn, reps)
+            rec = {"kernel": "%s[layer%d C=%d]" % (name, l, c_real), "ms": ms,
+                   "flops": work, "bytes": nbytes,
+                   "mfma_frac": work / ms / 1e9 / MFMA_PEAK_TFLOPS[dtype_name],
+                   "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBS}
+            # the roof that binds is the one the kernel sits closer to
+            if rec["mfma_frac"] > rec["hbm_frac"]:
+                rec.update(bound="mfma", achieved=work / ms / 1e9, peak=MFMA_PEAK_TFLOPS[dtype_name], unit="TFLOP/s",
+                           frac=rec["mfma_frac"])
             else:
-                rec.update(achieved=work / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s")
-            rec["frac"] = rec["achieved"] / rec["peak"]
+                rec.update(bound="hbm", achieved=nbytes / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=rec["hbm_frac"])
             out.append(rec)
     return out
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed counter passes (FETCH_SIZE and WRITE_SIZE need a profiler
+    run each, so they cannot be read inside the timed run): {kernel label: bytes}, empty when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return {k: v["hbm_bytes"] for k, v in json.load(f)["kernels"].items()}
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 def cpu_baseline_convlstm(model, batch, size, T, hist, head_size, budget_s=20.0):
@@ -204,8 +224,9 @@ def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
     res = {"rollouts_per_s": n / ms * 1e3, "ms_per_launch": ms, "rollouts": n, "size": size,
            "counts_only_rollouts_per_s": n / ms_counts * 1e3,
            "roofline": {"bound": "hbm", "achieved": n * bytes_per / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": n * bytes_per / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "raster_iou_kernel (masks materialised)"}}
+                        "frac": n * bytes_per / ms / 1e6 / HBM_PEAK_GBS,
+                        "traffic": load_pmc_traffic().get("raster_iou[masks]"),
+                        "algorithmic_bytes": n * bytes_per, "kernel": "raster_iou_kernel (masks materialised)"}}
     if do_cpu:
         import oracle
         lib = oracle.load_c()
@@ -254,6 +275,16 @@ def main():
                              head_size=head_size)
     T, hist = model.max_timesteps, model.history_length
     batch = make_batch(size, args.batch, T, hist, head_size, seed=rank, device=device, dtype=dtype)
+    if args.kernels_only:
+        # every label exactly 3 launches, in the order tools/pmc_traffic.py expects
+        time_kernels(model, batch, args.dtype, reps=2)
+        from imagesegmentation_amd import util
+        polys = [torch.from_numpy(a).to(device) for a in rollout_polygons(args.rollouts, size, 100 + rank)]
+        for want_masks in (True, False):
+            for _ in range(3):
+                util.raster_iou(*polys, size, want_masks=want_masks)
+        torch.cuda.synchronize()
+        return
 
     def step():
         return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
@@ -292,10 +323,13 @@ def main():
     kernels, roofline, cpu = None, None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = time_kernels(model, batch, args.dtype)
-        mf = [k for k in kernels if k["bound"] == "mfma"]
-        dom = max(mf, key=lambda k: k["ms"])
-        roofline = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
-                    "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "ms_per_launch": dom["ms"]}
+        traffic = load_pmc_traffic()
+        for k in kernels:
+            k["traffic"] = traffic.get(k["kernel"])
+        dom = max(kernels, key=lambda k: k["ms"])  # every kernel class runs T times per layer and step
+        roofline = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                    "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["kernel"],
+                    "ms_per_launch": dom["ms"], "algorithmic_bytes": dom["bytes"], "flops": dom["flops"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_convlstm(model, batch, size, T, hist, head_size)
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "isg_convlstm_wgrad_workspace_bytes": (_ll, [_int, _int]),
     "isg_convlstm_wgrad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _ll,
                                   _vp, _int, _vp, _vp, _vp, _vp]),
+    "isg_convlstm_wgrad_finish": (_int, [_vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -334,6 +334,8 @@ class _SequenceFunction(torch.autograd.Function):
             d_in = torch.zeros([B, H, W, cf], dtype=dt, device=dev)
             dx0_channels = cf
         seq._buf_t = None
+        # per-workgroup weight-gradient sums stay in a private workspace over the whole sweep
+        slabs = [ops.wgrad_workspace(packed[l].cs, F, dev, cached=False) for l in range(L)]
         for t in reversed(range(t_run)):
             x0 = seq.get(t)
             for l in reversed(range(L)):
@@ -345,7 +347,8 @@ class _SequenceFunction(torch.autograd.Function):
                 ops.pointwise_bwd(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l],
                                   durations_dev, t, dy=dy, dc_prev=dc_state[l])
                 ops.wgrad(x_in, Hs[l][t], dy, packed[l].c, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t,
-                          hist_points=seq.points(t) if l == 0 else None, hist=packed[l].hist)
+                          hist_points=seq.points(t) if l == 0 else None, hist=packed[l].hist,
+                          mode=ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST, workspace=slabs[l])
                 if l > 0:
                     ops.dgrad(dy, packed[l], dh_state[l], dx=dx_mid, dx_channels=F, durations=durations_dev, t=t)
                 elif seq.x_seq is not None:
@@ -356,6 +359,9 @@ class _SequenceFunction(torch.autograd.Function):
                               durations=durations_dev, t=t)
                 else:
                     raise NotImplementedError("static feature channels must be a multiple of 4")
+        if t_run > 0:
+            for l in range(L):
+                ops.wgrad_finish(slabs[l], (B, H, W, packed[l].cs), packed[l].c, packed[l].hist, *grads[l])
         if seq.x_seq is not None:
             d_input = d_in[..., :seq.C].to(ctx.in_dtype)
         else:

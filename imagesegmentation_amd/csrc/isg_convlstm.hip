@@ -235,58 +235,97 @@ struct PointwiseParams {
     int t, B, HW;
 };
 
+// CPT consecutive values as one vector load (CPT is 1 or 2; the address is CPT-element aligned)
+template <int CPT>
+__device__ __forceinline__ void load_run(const float* src, float (&v)[CPT]) {
+    if constexpr (CPT == 2) {
+        const float2 x = *reinterpret_cast<const float2*>(src);
+        v[0] = x.x, v[1] = x.y;
+    } else {
+        v[0] = src[0];
+    }
+}
+template <int CPT>
+__device__ __forceinline__ void load_run(const __bf16* src, float (&v)[CPT]) {
+    if constexpr (CPT == 2) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 x = *reinterpret_cast<const bf16x2*>(src);
+        v[0] = (float)x[0], v[1] = (float)x[1];
+    } else {
+        v[0] = (float)src[0];
+    }
+}
+
+// One thread takes the channels whose four gate values fill 16 bytes (2 for bf16, 1 for float), so
+// that every load and store of a wave covers whole, contiguous cache lines: a narrower split makes
+// the dy stores partial-sector writes, which cost twice the HBM write traffic.
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams p) {
-    const long long total = (long long)p.B * p.HW * (F_ / 4);
+    constexpr int CPT = sizeof(T) == 2 ? 2 : 1;  // channels per thread
+    constexpr int TPP = F_ / CPT;                // threads per pixel
+    const long long total = (long long)p.B * p.HW * TPP;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int q4 = (int)(idx & 3);
-        const long long pixel = idx >> 2;
+        const int q = (int)(idx % TPP);
+        const long long pixel = idx / TPP;
         const int b = (int)(pixel / p.HW);
-        const size_t so = (size_t)pixel * F_ + q4 * 4;
+        const size_t so = (size_t)pixel * F_ + q * CPT;
         const bool live = p.durations == nullptr || p.t < p.durations[b];
-        float dc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.dc_state) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.dc_state + so);
-            dc[0] = v[0], dc[1] = v[1], dc[2] = v[2], dc[3] = v[3];
-        }
-        T* dy = static_cast<T*>(p.dy) + (size_t)pixel * NG + q4 * 16;
+        float dc[CPT], gv[4 * CPT], out[4 * CPT], dcp[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) dc[k] = 0.0f;
+        if (p.dc_state) load_run<CPT>(p.dc_state + so, dc);
+        T* dy = static_cast<T*>(p.dy) + (size_t)pixel * NG + q * 4 * CPT;
         if (!live) {
-            const float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) store4(dy + 4 * k, z);
-            *reinterpret_cast<f32x4*>(p.dc_prev + so) = f32x4{dc[0], dc[1], dc[2], dc[3]};
-            continue;
-        }
-        float dh[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.dh_above) {
-            float v[4];
-            load4(static_cast<const T*>(p.dh_above) + (size_t)b * p.dh_above_bstride +
-                      (size_t)(pixel - (long long)b * p.HW) * F_ + q4 * 4, v);
-            dh[0] += v[0], dh[1] += v[1], dh[2] += v[2], dh[3] += v[3];
-        }
-        if (p.dh_state) {
-            float v[4];
-            load4(static_cast<const T*>(p.dh_state) + so, v);
-            dh[0] += v[0], dh[1] += v[1], dh[2] += v[2], dh[3] += v[3];
-        }
-        const f32x4 cpv = *reinterpret_cast<const f32x4*>(p.c_prev + so);
-        const f32x4 ccv = *reinterpret_cast<const f32x4*>(p.c_cur + so);
-        float dcp[4];
+            for (int k = 0; k < 4 * CPT; ++k) out[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float gv[4];
-            load4(static_cast<const T*>(p.gates) + (size_t)pixel * NG + q4 * 16 + 4 * k, gv);
-            const float g = gv[0], ig = gv[1], fg = gv[2], og = gv[3];
-            const float tc = tanh_t<T>(ccv[k]);
-            const float d_o = dh[k] * tc;
-            const float dct = dc[k] + dh[k] * og * (1.0f - tc * tc);
-            const float out[4] = {dct * ig * (1.0f - g * g), dct * g * ig * (1.0f - ig),
-                                  dct * cpv[k] * fg * (1.0f - fg), d_o * og * (1.0f - og)};
-            store4(dy + 4 * k, out);
-            dcp[k] = dct * fg;
+            for (int k = 0; k < CPT; ++k) dcp[k] = dc[k];
+        } else {
+            float dh[CPT], cpv[CPT], ccv[CPT];
+            const T* above = static_cast<const T*>(p.dh_above);
+            const T* state = static_cast<const T*>(p.dh_state);
+            const size_t ao = (size_t)b * p.dh_above_bstride + (size_t)(pixel - (long long)b * p.HW) * F_ + q * CPT;
+            float da[CPT], ds[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) da[k] = 0.0f, ds[k] = 0.0f;
+            if (above) load_run<CPT>(above + ao, da);
+            if (state) load_run<CPT>(state + so, ds);
+            load_run<CPT>(p.c_prev + so, cpv);
+            load_run<CPT>(p.c_cur + so, ccv);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) dh[k] = da[k] + ds[k];
+            const T* gp = static_cast<const T*>(p.gates) + (size_t)pixel * NG + q * 4 * CPT;
+            if constexpr (CPT == 2) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(gp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gv[k] = (float)x[k];
+            } else {
+                float v[4];
+                load4(gp, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[k] = v[k];
+            }
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const float g = gv[4 * k], ig = gv[4 * k + 1], fg = gv[4 * k + 2], og = gv[4 * k + 3];
+                const float tc = tanh_t<T>(ccv[k]);
+                const float d_o = dh[k] * tc;
+                const float dct = dc[k] + dh[k] * og * (1.0f - tc * tc);
+                out[4 * k] = dct * ig * (1.0f - g * g);
+                out[4 * k + 1] = dct * g * ig * (1.0f - ig);
+                out[4 * k + 2] = dct * cpv[k] * fg * (1.0f - fg);
+                out[4 * k + 3] = d_o * og * (1.0f - og);
+                dcp[k] = dct * fg;
+            }
         }
-        *reinterpret_cast<f32x4*>(p.dc_prev + so) = f32x4{dcp[0], dcp[1], dcp[2], dcp[3]};
+        if constexpr (CPT == 2) {
+            store8(dy, out);
+            *reinterpret_cast<float2*>(p.dc_prev + so) = float2{dcp[0], dcp[1]};
+        } else {
+            store4(dy, reinterpret_cast<const float(&)[4]>(out));
+            p.dc_prev[so] = dcp[0];
+        }
     }
 }
 
@@ -424,13 +463,17 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                slab[((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31)] = acc[i][reg];
+                float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31);
+                *dst = p.slab_accumulate ? *dst + acc[i][reg] : acc[i][reg];
             }
         }
     }
     if (does_bias) {
         bsum += __shfl_xor(bsum, 32);
-        if (half == 0) p.bias_slab[(size_t)blockIdx.x * NG + 32 * nt + lane] = bsum;
+        if (half == 0) {
+            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * nt + lane;
+            *dst = p.slab_accumulate ? *dst + bsum : bsum;
+        }
     }
 }
 
@@ -648,8 +691,8 @@ extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride;
     p.dh_state = dh_state, p.dc_state = dc_state, p.dc_prev = dc_prev, p.dy = dy;
     p.durations = durations, p.t = t, p.B = B, p.HW = H * W;
-    const long long total = (long long)B * H * W * (F_ / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const long long total = (long long)B * H * W * (dtype == ISG_F32 ? F_ : F_ / 2);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32)
         hipLaunchKernelGGL(lstm_pointwise_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
@@ -717,11 +760,15 @@ extern "C" long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F) {
 extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C,
                                   int Cs, int F, int dtype, const int32_t* durations, int t,
                                   const int32_t* hist_points, int hist, long long hist_batch_stride, void* workspace,
-                                  int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream) {
+                                  int mode, float* dw_x, float* dw_h, float* dbias, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(x && h_prev && dy && workspace && dw_x && dw_h && dbias, ISG_EINVAL,
                 "isg_convlstm_wgrad: null pointer");
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= Cs, ISG_EINVAL, "isg_convlstm_wgrad: bad shape");
+    ISG_REQUIRE(mode >= ISG_WGRAD_ASSIGN && mode <= ISG_WGRAD_DEFER, ISG_EINVAL, "isg_convlstm_wgrad: bad mode %d",
+                mode);
+    const bool deferred = mode == ISG_WGRAD_DEFER_FIRST || mode == ISG_WGRAD_DEFER;
+    const int accumulate = mode == ISG_WGRAD_ADD || mode == ISG_WGRAD_DEFER;
     int rc = check_channels("isg_convlstm_wgrad", Cs, dtype);
     if (rc != ISG_OK) return rc;
     ISG_REQUIRE(Cs + F_ <= 64, ISG_EINVAL, "isg_convlstm_wgrad: at most %d input channels (got %d)", 64 - F_, Cs);
@@ -735,6 +782,7 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
     const int grid = ntiles < kWgradMaxBlocks ? ntiles : kWgradMaxBlocks;
     p.slab = static_cast<float*>(workspace);
     p.bias_slab = p.slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
+    p.slab_accumulate = mode == ISG_WGRAD_DEFER;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t esz = dtype == ISG_F32 ? 4 : 2, pad = dtype == ISG_F32 ? 4 : 16;
     const size_t lds = (((size_t)NPX * ((Cs + F_) * esz + pad) + 15) & ~(size_t)15) + (size_t)TH * TW * (NG * esz + pad);
@@ -765,10 +813,12 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
         }
     }
     if ((rc = isg::check_launch("conv_wgrad_kernel")) != ISG_OK) return rc;
-    const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, p.bias_slab, grid, MT,
-                       C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
-    if ((rc = isg::check_launch("wgrad_reduce_kernel")) != ISG_OK) return rc;
+    if (!deferred) {
+        const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, p.bias_slab, grid,
+                           MT, C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
+        if ((rc = isg::check_launch("wgrad_reduce_kernel")) != ISG_OK) return rc;
+    }
     if (hist > 0) {
         ISG_REQUIRE(hist_points, ISG_EINVAL, "isg_convlstm_wgrad: history points are needed when hist > 0");
         if (dtype == ISG_F32)
@@ -781,4 +831,21 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
         rc = isg::check_launch("hist_wgrad_kernel");
     }
     return rc;
+}
+
+extern "C" int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C, int Cs, int hist, int F,
+                                         int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream) {
+    ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(workspace && dw_x && dw_h && dbias, ISG_EINVAL, "isg_convlstm_wgrad_finish: null pointer");
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= Cs && hist >= 0 && Cs + F_ <= 64, ISG_EINVAL,
+                "isg_convlstm_wgrad_finish: bad shape");
+    const int MT = (Cs + F_ + 31) / 32;
+    const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int grid = ntiles < kWgradMaxBlocks ? ntiles : kWgradMaxBlocks;
+    const float* slab = static_cast<const float*>(workspace);
+    const float* bias_slab = slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
+    const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       slab, bias_slab, grid, MT, C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
+    return isg::check_launch("wgrad_reduce_kernel");
 }

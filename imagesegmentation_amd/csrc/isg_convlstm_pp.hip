@@ -582,13 +582,17 @@ __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                slab[((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31)] = acc[i][reg];
+                float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31);
+                *dst = p.slab_accumulate ? *dst + acc[i][reg] : acc[i][reg];
             }
         }
     }
     if (does_bias) {
         bsum += __shfl_xor(bsum, 32);
-        if (half == 0) p.bias_slab[(size_t)blockIdx.x * NG + 32 * nt + lane] = bsum;
+        if (half == 0) {
+            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * nt + lane;
+            *dst = p.slab_accumulate ? *dst + bsum : bsum;
+        }
     }
 }
 

@@ -286,6 +286,7 @@ struct WgradParams {
     int t;
     float* slab;       // [gridDim.x][9][MT*32][64]
     float* bias_slab;  // [gridDim.x][64]
+    int slab_accumulate;  // add to what the slabs hold (sums deferred over several launches)
 };
 
 // bf16 ping-pong fast path (isg_convlstm_pp.hip).  Returns ISG_OK, an error, or kNotSupported when

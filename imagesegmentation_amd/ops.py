@@ -125,29 +125,50 @@ def dgrad(dy, packed, dh_prev, dx=None, dx_channels=0, dx_accumulate=False, dura
 
 _workspaces = {}
 
+WGRAD_ASSIGN, WGRAD_ADD, WGRAD_DEFER_FIRST, WGRAD_DEFER = 0, 1, 2, 3
 
-def wgrad_workspace(cs, f, device):
+
+def wgrad_workspace(cs, f, device, cached=True):
+    """Scratch for the per-workgroup partial sums; ``cached=False`` gives a private one (needed
+    when sums are deferred over several launches)."""
     key = (cs, f, str(device))
-    ws = _workspaces.get(key)
+    ws = _workspaces.get(key) if cached else None
     if ws is None:
         nbytes = _lib.lib().isg_convlstm_wgrad_workspace_bytes(cs, f)
         if nbytes < 0:
             raise _lib.IsgError("weight gradient supports at most %d input channels (got %d)" % (64 - f, cs))
         ws = torch.empty([nbytes // 4], dtype=torch.float32, device=device)
-        _workspaces[key] = ws
+        if cached:
+            _workspaces[key] = ws
     return ws
 
 
-def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0, hist_points=None, hist=0):
+def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0, hist_points=None, hist=0,
+          mode=None, workspace=None):
     """Parameter gradients of one step into float32 dw_x [3,3,C+hist,4F], dw_h [3,3,F,4F], dbias [4F];
-    c_real = channels of x that went through the GEMM."""
+    c_real = channels of x that went through the GEMM.  ``mode`` (one of the WGRAD_* codes)
+    overrides ``accumulate``; the deferred modes need a private ``workspace`` and a closing
+    ``wgrad_finish``."""
     B, H, W, Cs = x.shape
     F = h_prev.shape[-1]
-    ws = wgrad_workspace(Cs, F, x.device)
+    if mode is None:
+        mode = WGRAD_ADD if accumulate else WGRAD_ASSIGN
+    if workspace is None:
+        if mode in (WGRAD_DEFER_FIRST, WGRAD_DEFER):
+            raise ValueError("deferred weight-gradient sums need their own workspace")
+        workspace = wgrad_workspace(Cs, F, x.device)
     pts, pts_stride = _points_arg(hist_points, hist)
     rc = _lib.lib().isg_convlstm_wgrad(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(dy), B, H, W, int(c_real), Cs, F,
                                        dtype_code(x.dtype), _lib.ptr(durations), int(t), pts, int(hist), pts_stride,
-                                       _lib.ptr(ws),
-                                       int(bool(accumulate)), _lib.ptr(dw_x), _lib.ptr(dw_h), _lib.ptr(dbias),
-                                       _lib.current_stream())
+                                       _lib.ptr(workspace), int(mode), _lib.ptr(dw_x), _lib.ptr(dw_h),
+                                       _lib.ptr(dbias), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_wgrad")
+
+
+def wgrad_finish(workspace, shape, c_real, hist, dw_x, dw_h, dbias, accumulate=False):
+    """Fold the partial sums left by deferred ``wgrad`` calls over inputs of ``shape`` [B,H,W,Cs]."""
+    B, H, W, Cs = shape
+    rc = _lib.lib().isg_convlstm_wgrad_finish(_lib.ptr(workspace), B, H, W, int(c_real), Cs, int(hist),
+                                              dw_h.shape[2], int(bool(accumulate)), _lib.ptr(dw_x), _lib.ptr(dw_h),
+                                              _lib.ptr(dbias), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_wgrad_finish")

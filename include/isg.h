@@ -140,13 +140,23 @@ int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int B, int H, i
                        int dx_accumulate, void* dh_prev, void* stream);
 
 /* Backward, step 3 (parameter gradients): dw_x [3][3][C + hist][4F], dw_h [3][3][F][4F], dbias [4F],
- * all float, overwritten or (accumulate != 0) added to.  workspace: device scratch of
- * isg_convlstm_wgrad_workspace_bytes(Cs, F) bytes; needs Cs + F <= 64. */
+ * all float.  workspace: device scratch of isg_convlstm_wgrad_workspace_bytes(Cs, F) bytes holding one
+ * partial sum per workgroup; needs Cs + F <= 64.  mode:
+ *   ISG_WGRAD_ASSIGN       dw = this step's gradient
+ *   ISG_WGRAD_ADD          dw += this step's gradient
+ *   ISG_WGRAD_DEFER_FIRST  the partial sums stay in the workspace (overwriting it); dw_h, dbias and the C
+ *                          GEMM channels of dw_x are not touched; the hist channels of dw_x are assigned
+ *   ISG_WGRAD_DEFER        as above but added to the workspace / to the hist channels of dw_x
+ * After a run of deferred calls with one workspace (same B, H, W, Cs), isg_convlstm_wgrad_finish folds
+ * the partial sums into dw (accumulate != 0: adds) - one reduction per sequence instead of one per step. */
+enum { ISG_WGRAD_ASSIGN = 0, ISG_WGRAD_ADD = 1, ISG_WGRAD_DEFER_FIRST = 2, ISG_WGRAD_DEFER = 3 };
 long long isg_convlstm_wgrad_workspace_bytes(int Cs, int F);
 int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B, int H, int W, int C, int Cs, int F,
                        int dtype, const int32_t* durations, int t, const int32_t* hist_points, int hist,
-                       long long hist_batch_stride, void* workspace, int accumulate, float* dw_x, float* dw_h,
+                       long long hist_batch_stride, void* workspace, int mode, float* dw_x, float* dw_h,
                        float* dbias, void* stream);
+int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C, int Cs, int hist, int F,
+                              int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream);
 
 /* ---- vertex decoding over the class grid ----------------------------------------------------
  * logits: `dtype` [rows][cols] (cols = P*P or P*P + 1).  One wave per row.

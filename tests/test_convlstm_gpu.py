@@ -180,3 +180,35 @@ def test_tiled_features_plus_history_input(dtype, dense):
     for l in range(L):
         close(multi.cells[l].input_to_state_kernel.grad, grads[l]["dw_x"], dtype, "dw_x[%d]" % l)
         close(multi.cells[l].bias.grad, grads[l]["dbias"], dtype, "dbias[%d]" % l)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_weight_gradient_sums_match_per_step_accumulation(dtype):
+    """Three steps folded once at the end (partial sums kept in the workspace) against three
+    per-step reductions added into dw; ragged durations so that some tiles are masked."""
+    from imagesegmentation_amd import ops
+    rs = np.random.RandomState(5)
+    B, H, W, C, Cs, hist = 3, 20, 40, 18, 32, 2
+    t32 = lambda a: torch.tensor(a, dtype=torch.float32, device=dev())
+    durations = torch.tensor([3, 1, 2], dtype=torch.int32, device=dev())
+    pts = torch.tensor(rs.randint(-1, 20, size=(3, B, hist, 2)), dtype=torch.int32, device=dev())
+    steps = []
+    for t in range(3):
+        x = t32(rs.randn(B, H, W, Cs)).to(dtype)
+        x[..., C:] = 0
+        steps.append((x, t32(rs.randn(B, H, W, 16)).to(dtype), t32(rs.randn(B, H, W, 16, 4)).to(dtype)))
+    mk = lambda: (torch.zeros([3, 3, C + hist, 64], device=dev()), torch.zeros([3, 3, 16, 64], device=dev()),
+                  torch.zeros([64], device=dev()))
+    ref, got = mk(), mk()
+    for t, (x, h, dy) in enumerate(steps):
+        ops.wgrad(x, h, dy, C, *ref, True, durations, t, hist_points=pts[t], hist=hist)
+    ws = ops.wgrad_workspace(Cs, 16, dev(), cached=False)
+    for t, (x, h, dy) in enumerate(steps):
+        ops.wgrad(x, h, dy, C, *got, True, durations, t, hist_points=pts[t], hist=hist,
+                  mode=ops.WGRAD_DEFER if t else ops.WGRAD_DEFER_FIRST, workspace=ws)
+    ops.wgrad_finish(ws, (B, H, W, Cs), C, hist, *got)
+    for a, b, name in zip(got, ref, ("dw_x", "dw_h", "dbias")):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-5 * scale, name
+    with pytest.raises(ValueError):
+        ops.wgrad(*steps[0], C, *got, True, mode=ops.WGRAD_DEFER)
