@@ -45,8 +45,9 @@ class ConvLSTMCell(torch.nn.Module):
         super().__init__()
         if list(kernel) != [3, 3]:
             raise NotImplementedError("the HIP cell implements the reference's 3x3 kernel only")
-        if filters != ops.F_HIDDEN:
-            raise NotImplementedError("the HIP cell implements the reference's 16 filters only")
+        if filters <= 0 or filters % ops.F_HIDDEN != 0:
+            raise NotImplementedError("the HIP cell takes filters in multiples of %d (the reference's nets use 16, "
+                                      "its a3c policy 32)" % ops.F_HIDDEN)
         self._kernel = list(kernel)
         self._filters = int(filters)
         self._initializer = initializer
@@ -112,16 +113,49 @@ class ConvLSTMCell(torch.nn.Module):
         """One step: x [B, H, W, C]; h = (c, h) state tuple.  Returns (output, LSTMStateTuple(c, h))."""
         previous_memory, previous_output = h
         self.build(x.shape[-1], x.device)
+        if self._filters != ops.F_HIDDEN:
+            return self._forward_wide(x, previous_memory, previous_output)
         new_h, new_c = _CellFunction.apply(x, previous_memory, previous_output, self.input_to_state_kernel,
                                            self.hidden_to_state_kernel, self.bias, self)
         return new_h, LSTMStateTuple(new_c, new_h)
 
 
+    def _forward_wide(self, x, c_prev, h_prev):
+        """filters = 16 k (k > 1) as k launches of the 16-filter kernels: output channels
+        [16 s, 16 s + 16) depend on all of x and all of h_prev but on no other output channel, so
+        group s is a 16-filter cell whose input is x joined with h_prev[16:] (their weights joined
+        the same way), whose recurrent input is h_prev[:16], and whose gate columns are the
+        group's columns of each j|i|f|o block."""
+        Fh, F = ops.F_HIDDEN, self._filters
+        if x.shape[-1] + F - Fh > 64 - Fh:
+            raise NotImplementedError("a %d-filter cell takes at most %d input channels" % (F, 64 - F))
+        dt = self.compute_dtype
+        x_wide = torch.cat([x.to(dt), h_prev[..., Fh:].to(dt)], dim=-1)
+        h_head = h_prev[..., :Fh]
+        hs, cs = [], []
+        for s in range(F // Fh):
+            cols = torch.cat([torch.arange(g * F + Fh * s, g * F + Fh * s + Fh) for g in range(4)]).to(x.device)
+            w_h_cols = self.hidden_to_state_kernel.index_select(3, cols)
+            w_x = torch.cat([self.input_to_state_kernel.index_select(3, cols), w_h_cols[:, :, Fh:]], dim=2)
+            h_s, c_s = _CellFunction.apply(x_wide, c_prev[..., Fh * s:Fh * s + Fh], h_head, w_x,
+                                           w_h_cols[:, :, :Fh].contiguous(), self.bias.index_select(0, cols), None,
+                                           dt)
+            hs.append(h_s)
+            cs.append(c_s)
+        new_h, new_c = torch.cat(hs, dim=-1), torch.cat(cs, dim=-1)
+        return new_h, LSTMStateTuple(new_c, new_h)
+
+
 class _CellFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c_prev, h_prev, w_x, w_h, bias, cell):
-        dt = cell.compute_dtype
-        packed = cell.packed()
+    def forward(ctx, x, c_prev, h_prev, w_x, w_h, bias, cell, dtype=None):
+        if cell is not None:
+            dt = cell.compute_dtype
+            packed = cell.packed()
+        else:  # one group of a wide cell: weights are slices, packed per call
+            dt = dtype
+            packed = ops.PackedWeights(w_x.detach(), w_h.detach(), bias.detach(),
+                                       ops.padded_channels(w_x.shape[2], dt), dt)
         xs = _pad_channels(x.to(dt), packed.cs)
         hp = h_prev.to(dt).contiguous()
         cp = c_prev.to(torch.float32).contiguous()
@@ -150,7 +184,7 @@ class _CellFunction(torch.autograd.Function):
         dh_prev = torch.empty_like(hp)
         ops.dgrad(dy, packed, dh_prev, dx=dx, dx_channels=packed.cs)
         xd, cd, hd = ctx.in_dtypes
-        return dx[..., :ctx.c_real].to(xd), dc_prev.to(cd), dh_prev.to(hd), dw_x, dw_h, dbias, None
+        return dx[..., :ctx.c_real].to(xd), dc_prev.to(cd), dh_prev.to(hd), dw_x, dw_h, dbias, None, None
 
 
 class MultiRNNCell(torch.nn.Module):
@@ -375,6 +409,30 @@ class _SequenceFunction(torch.autograd.Function):
         return tuple(result)
 
 
+def _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state):
+    """Step-by-step recurrence through ``cell.forward`` (autograd records every step); used for
+    cells wider than 16 filters, which the fused sequence node does not take.  Same masking rule:
+    past a sample's length the output is zero and the state is carried through."""
+    if seq.x_seq is None:
+        raise NotImplementedError("wide cells take a time-major tensor input")
+    state = [LSTMStateTuple(c, h) for c, h in initial_state]
+    dt = multi.cells[0].compute_dtype
+    outs = []
+    for t in range(seq.T):
+        if t >= t_run:
+            outs.append(torch.zeros([seq.B, seq.H, seq.W, multi.cells[-1]._filters], dtype=dt, device=seq.x_seq.device))
+            continue
+        x, new_state = multi(seq.x_seq[t], tuple(state))
+        if durations_dev is not None:
+            live = (durations_dev > t).view(-1, 1, 1, 1)
+            x = torch.where(live, x, torch.zeros_like(x))
+            new_state = [LSTMStateTuple(torch.where(live, n.c, o.c.to(n.c.dtype)), torch.where(live, n.h, o.h.to(n.h.dtype)))
+                         for n, o in zip(new_state, state)]
+        state = list(new_state)
+        outs.append(x)
+    return torch.stack(outs, dim=1), tuple(state)
+
+
 def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True):
     """``tf.nn.dynamic_rnn`` for a ``MultiRNNCell`` (or a single cell) of ConvLSTM cells.
 
@@ -411,6 +469,11 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
         initial_state = multi.zero_state(B, dev)
     elif not isinstance(initial_state[0], (tuple, list)):
         initial_state = (initial_state,)
+    if any(c._filters != ops.F_HIDDEN for c in multi.cells):
+        out, final = _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state)
+        if time_major:
+            out = out.transpose(0, 1)
+        return out, (final if isinstance(cell, MultiRNNCell) else final[0])
     tensors = [diff_input]
     for c, h in initial_state:
         tensors += [c, h]

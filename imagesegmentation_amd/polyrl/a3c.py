@@ -1,0 +1,252 @@
+"""The actor-critic of the reference's polyrl/a3c directory, run synchronously over batched environments.
+
+The reference code is a specification that never ran (its policy passes ``height=``/``width=`` to a
+cell that takes ``shape=``, polyrl/a3c/model.py:23, and its worker imports a missing ``envs`` module).
+What it specifies is kept:
+
+* policy (polyrl/a3c/model.py:13-44): 4 x conv(32, 3x3, same, relu) -> ConvLSTM(32 filters, 3x3) over the
+  rollout as the time axis -> ``logits = dense(ac_space)``, ``vf = dense(1)`` on the flattened output;
+  sampling = multinomial over the logits (:8-10);
+* returns and advantages (polyrl/a3c/a3c.py:11-32): discounted returns, GAE with lambda = 1;
+* loss (polyrl/a3c/a3c.py:201-216): ``-sum(log pi(a) adv) + 0.5 * 0.5 * sum((vf - R)^2) - 0.01 * H``;
+* update (polyrl/a3c/a3c.py:248-258): clip_by_global_norm(40), Adam(1e-4);
+* the runner's episode rule (polyrl/a3c/a3c.py:150-159): a rollout ends at the terminal step or after 10
+  steps, whichever comes first, so it always ends an episode and its bootstrap value is 0.
+
+What is not reproduced: asynchronous workers around a parameter server.  Here every rank steps
+``num_envs`` environments in lock-step (the rollouts are the batch axis, their steps the time axis),
+the per-rollout losses are averaged, and ranks exchange ONE all-reduce of the flat gradient.
+The env adapter ``action -> (a // P, a % P)`` (x-major, as the class index of polyrnn/Model.py:39) is
+this build's; the reference hands ``action.argmax()`` to an environment that expects a point.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..convLSTM import ConvLSTMCell, LSTMStateTuple, dynamic_rnn, glorot_uniform_
+from ..optim import FlatAdam
+from ..polyrnn import decode
+
+
+def discount(x, gamma):
+    """y[t] = x[t] + gamma * y[t+1] along axis 0 (reference polyrl/a3c/a3c.py:11-12, which spells it
+    as scipy.signal.lfilter([1], [1, -gamma]) on the reversed sequence)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    acc = np.zeros_like(x[0]) if x.ndim > 1 else 0.0
+    for t in range(len(x) - 1, -1, -1):
+        acc = x[t] + gamma * acc
+        y[t] = acc
+    return y
+
+
+def process_rollout(rewards, values, bootstrap, gamma, lambda_=1.0):
+    """(advantages, returns) of one rollout (reference polyrl/a3c/a3c.py:15-32)."""
+    rewards = np.asarray(rewards, dtype=np.float64)
+    vpred_t = np.asarray(list(values) + [bootstrap], dtype=np.float64)
+    rewards_plus_v = np.asarray(list(rewards) + [bootstrap], dtype=np.float64)
+    batch_r = discount(rewards_plus_v, gamma)[:-1]
+    td_error = rewards + gamma * vpred_t[1:] - vpred_t[:-1]
+    return discount(td_error, gamma * lambda_), batch_r
+
+
+def process_rollouts(rewards, values, lengths, gamma, lambda_=1.0, bootstrap=None):
+    """The same for N rollouts held as device tensors [N, T] with per-rollout lengths: entries at
+    t >= length are ignored on input and zero on output.  float64 throughout."""
+    N, T = rewards.shape
+    dev = rewards.device
+    live = torch.arange(T, device=dev)[None, :] < lengths[:, None]
+    rewards = torch.where(live, rewards.double(), torch.zeros([], dtype=torch.float64, device=dev))
+    values = torch.where(live, values.double(), torch.zeros([], dtype=torch.float64, device=dev))
+    boot = torch.zeros([N], dtype=torch.float64, device=dev) if bootstrap is None else bootstrap.double()
+    last = (lengths.long() - 1).clamp(min=0)
+    # v[t+1], with the bootstrap value after the last live step
+    v_next = torch.cat([values[:, 1:], torch.zeros([N, 1], dtype=torch.float64, device=dev)], dim=1)
+    v_next[torch.arange(N, device=dev), last] = boot
+    v_next = torch.where(live, v_next, torch.zeros_like(v_next))
+    td = rewards + gamma * v_next - values
+    r_in = rewards.clone()
+    r_in[torch.arange(N, device=dev), last] += gamma * boot * (lengths > 0)
+    adv, ret = torch.zeros_like(td), torch.zeros_like(td)
+    acc_a = torch.zeros([N], dtype=torch.float64, device=dev)
+    acc_r = torch.zeros([N], dtype=torch.float64, device=dev)
+    for t in range(T - 1, -1, -1):
+        acc_a = torch.where(live[:, t], td[:, t] + gamma * lambda_ * acc_a, acc_a)
+        acc_r = torch.where(live[:, t], r_in[:, t] + gamma * acc_r, acc_r)
+        adv[:, t], ret[:, t] = acc_a, acc_r
+    zero = torch.zeros_like(adv)
+    return torch.where(live, adv, zero), torch.where(live, ret, zero)
+
+
+def a3c_loss(logits, vf, actions, adv, r, live=None):
+    """Reference polyrl/a3c/a3c.py:201-216 over rows [R, K] (R = all steps of all rollouts); rows with
+    ``live`` False contribute nothing.  Returns (loss, dict of the three parts), all sums."""
+    logp = F.log_softmax(logits.float(), dim=-1)
+    p = logp.exp()
+    w = torch.ones_like(vf, dtype=torch.float32) if live is None else live.to(torch.float32)
+    chosen = logp.gather(1, actions.long()[:, None])[:, 0]
+    pi_loss = -(chosen * adv.float() * w).sum()
+    vf_loss = 0.5 * (((vf.float() - r.float()) ** 2) * w).sum()
+    entropy = -((p * logp).sum(dim=1) * w).sum()
+    return pi_loss + 0.5 * vf_loss - entropy * 0.01, dict(pi_loss=pi_loss, vf_loss=vf_loss, entropy=entropy)
+
+
+def _dense_init(shape, device, gen):
+    limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+    return (torch.rand(shape, device=device, generator=gen) * 2 - 1) * limit
+
+
+class LSTMPolicy:
+    """Reference polyrl/a3c/model.py:13-68 for N environments at once: ``x`` is [N, T, H, W, C]."""
+
+    def __init__(self, ob_space, ac_space, filters=32, compute_dtype=torch.float32, device=None, seed=0):
+        H, W, C = ob_space
+        self.ob_space, self.ac_space, self.filters = tuple(ob_space), int(ac_space), int(filters)
+        self.compute_dtype = compute_dtype
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        self.convs = []
+        cin = C
+        for _ in range(4):
+            w = torch.empty([3, 3, cin, 32], device=self.device)
+            limit = math.sqrt(6.0 / (9 * cin + 9 * 32))
+            w.copy_((torch.rand(w.shape, device=self.device, generator=gen) * 2 - 1) * limit)
+            self.convs.append((torch.nn.Parameter(w), torch.nn.Parameter(torch.zeros([32], device=self.device))))
+            cin = 32
+        init = lambda t: t.copy_(glorot_uniform_(torch.empty_like(t)))
+        self.lstm = ConvLSTMCell(shape=[H, W], filters=self.filters, kernel=[3, 3], initializer=init,
+                                 compute_dtype=compute_dtype, device=self.device)
+        self.lstm.build(cin, self.device)
+        self.state_size = self.lstm.state_size
+        flat = H * W * self.filters
+        self.action_kernel = torch.nn.Parameter(_dense_init((flat, self.ac_space), self.device, gen))
+        self.action_bias = torch.nn.Parameter(torch.zeros([self.ac_space], device=self.device))
+        self.value_kernel = torch.nn.Parameter(_dense_init((flat, 1), self.device, gen))
+        self.value_bias = torch.nn.Parameter(torch.zeros([1], device=self.device))
+        self._sample_calls = 0
+        self._seed = seed
+
+    @property
+    def var_list(self):
+        out = []
+        for w, b in self.convs:
+            out += [w, b]
+        out += [self.lstm.hidden_to_state_kernel, self.lstm.input_to_state_kernel, self.lstm.bias,
+                self.action_kernel, self.action_bias, self.value_kernel, self.value_bias]
+        return out
+
+    def named_variables(self, scope="global"):
+        names = []
+        for i in range(4):
+            names += ["%s/l%d/kernel" % (scope, i + 1), "%s/l%d/bias" % (scope, i + 1)]
+        base = "%s/rnn/ConvLSTMCell/" % scope
+        names += [base + "hidden_to_state_kernel", base + "input_to_state_kernel", base + "bias",
+                  "%s/action/kernel" % scope, "%s/action/bias" % scope, "%s/value/kernel" % scope,
+                  "%s/value/bias" % scope]
+        return list(zip(names, self.var_list))
+
+    def get_initial_features(self, num_envs=1):
+        """Zero LSTM state (c float32, h compute dtype), reference polyrl/a3c/model.py:27-29,46-48."""
+        return self.lstm.zero_state(num_envs, self.device)
+
+    def _encode(self, x):
+        # [R, H, W, C] -> [R, H, W, 32]
+        dt = self.compute_dtype
+        y = x.to(dt).permute(0, 3, 1, 2)
+        for w, b in self.convs:
+            wk = w.to(dt).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+            y = F.relu(F.conv2d(y, wk, b.to(dt), padding=1))
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    def forward(self, x, state):
+        """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out."""
+        N, T = x.shape[0], x.shape[1]
+        feats = self._encode(x.reshape((N * T,) + tuple(x.shape[2:]))).reshape((N, T) + tuple(x.shape[2:4]) + (32,))
+        out, final = dynamic_rnn(self.lstm, feats, initial_state=LSTMStateTuple(*state), time_major=False)
+        flat = out.reshape(N * T, -1)
+        dt = flat.dtype
+        logits = torch.addmm(self.action_bias.to(dt), flat, self.action_kernel.to(dt)).float().reshape(N, T, -1)
+        vf = torch.addmm(self.value_bias.to(dt), flat, self.value_kernel.to(dt)).float().reshape(N, T)
+        return logits, vf, final
+
+    def act(self, ob, c, h):
+        """One step for N environments: (action index int64 [N], value [N], c, h)
+        (reference polyrl/a3c/model.py:50-63, whose action is the one-hot of the same index)."""
+        with torch.no_grad():
+            logits, vf, (c2, h2) = self.forward(ob[:, None], (c, h))
+            self._sample_calls += 1
+            a = decode.sample_rows(logits[:, 0].contiguous(), seed=self._seed * 1000003 + self._sample_calls)
+        return a.long(), vf[:, 0], c2, h2
+
+    def value(self, ob, c, h):
+        with torch.no_grad():
+            return self.forward(ob[:, None], (c, h))[1][:, 0]
+
+
+class A3C:
+    """Synchronous, sharded replacement of reference polyrl/a3c/a3c.py:168-302: ``process()`` runs one
+    rollout per environment, then one update."""
+
+    TIMESTEP_LIMIT = 10  # reference polyrl/a3c/a3c.py:150
+
+    def __init__(self, env, policy=None, gamma=0.99, lambda_=1.0, learning_rate=1e-4, process_group=None,
+                 compute_dtype=torch.float32, seed=0):
+        self.env = env
+        P = env.size
+        if policy is None:
+            policy = LSTMPolicy((P, P, 3 + env.hist), P * P, compute_dtype=compute_dtype, device=env.device, seed=seed)
+        self.network = self.local_network = policy  # one copy: the sync of :251,281 is the identity
+        self.gamma, self.lambda_ = gamma, lambda_
+        self.opt = FlatAdam(policy.var_list, learning_rate=learning_rate, clip_norm=40.0, process_group=process_group)
+        self.global_step = 0
+        self.local_steps = 0
+        self.last = {}
+
+    def pull_batch(self, images=None, polygons=None):
+        """Every environment from reset to its terminal step or the step limit."""
+        env, pi = self.env, self.local_network
+        N, T, P = env.num_envs, self.TIMESTEP_LIMIT, env.size
+        dev = env.device
+        state = env.reset(images=images, polygons=polygons)
+        c, h = pi.get_initial_features(N)
+        obs = torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev)
+        actions = torch.zeros([N, T], dtype=torch.int64, device=dev)
+        values = torch.zeros([N, T], dtype=torch.float32, device=dev)
+        rewards = torch.zeros([N, T], dtype=torch.float64, device=dev)
+        lengths = torch.zeros([N], dtype=torch.int32, device=dev)
+        for t in range(T):
+            active = ~env.done
+            if not bool(active.any()):
+                break
+            obs[:, t] = state
+            a, v, c, h = pi.act(state, c, h)
+            actions[:, t], values[:, t] = a, v
+            lengths += active.to(torch.int32)
+            xy = torch.stack([a // P, a % P], dim=1)
+            state, reward, _ = env.step(xy)
+            rewards[:, t] = reward
+        return dict(si=obs, a=actions, values=values, rewards=rewards, lengths=lengths, terminal=env.done.clone())
+
+    def process(self, images=None, polygons=None):
+        pi = self.local_network
+        batch = self.pull_batch(images, polygons)
+        N, T = batch["a"].shape
+        adv, r = process_rollouts(batch["rewards"], batch["values"], batch["lengths"], self.gamma, self.lambda_)
+        live = torch.arange(T, device=adv.device)[None, :] < batch["lengths"][:, None]
+        self.opt.zero_grad()
+        logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N))
+        loss, parts = a3c_loss(logits.reshape(N * T, -1), vf.reshape(-1), batch["a"].reshape(-1), adv.reshape(-1),
+                               r.reshape(-1), live.reshape(-1))
+        (loss / N).backward()
+        norm = self.opt.step()
+        self.global_step += int(batch["lengths"].sum())
+        self.local_steps += 1
+        bs = float(batch["lengths"].sum().clamp(min=1))
+        self.last = dict(loss=float(loss) / N, grad_global_norm=float(norm),
+                         policy_loss=float(parts["pi_loss"]) / bs, value_loss=float(parts["vf_loss"]) / bs,
+                         entropy=float(parts["entropy"]) / bs,
+                         episode_reward=float(batch["rewards"].sum(dim=1).mean()))
+        return batch

@@ -212,3 +212,46 @@ def test_deferred_weight_gradient_sums_match_per_step_accumulation(dtype):
         assert (a - b).abs().max().item() <= 1e-5 * scale, name
     with pytest.raises(ValueError):
         ops.wgrad(*steps[0], C, *got, True, mode=ops.WGRAD_DEFER)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wide_cell_32_filters_forward_backward(dtype):
+    """filters = 32 (the reference's a3c policy, polyrl/a3c/model.py:21-23) runs as two 16-filter
+    groups; one step and a masked 3-step recurrence against the oracle."""
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell, dynamic_rnn
+    rs = np.random.RandomState(23)
+    T, B, H, W, C, F = 3, 3, 12, 20, 32, 32
+    w_x, w_h, bias = rand_cell(rs, C, F=F)
+    cell = ConvLSTMCell(shape=[H, W], filters=F, kernel=[3, 3], compute_dtype=dtype, device=dev())
+    cell.build(C, dev())
+    with torch.no_grad():
+        cell.input_to_state_kernel.copy_(torch.tensor(w_x))
+        cell.hidden_to_state_kernel.copy_(torch.tensor(w_h))
+        cell.bias.copy_(torch.tensor(bias))
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    x = rs.randn(T, B, H, W, C)
+    durations = np.array([3, 1, 2], np.int32)
+    init = [(rs.randn(B, H, W, F) * 0.3, rs.randn(B, H, W, F) * 0.3)]
+    d_out = rs.randn(T, B, H, W, F)
+    d_fin = [(rs.randn(B, H, W, F), rs.randn(B, H, W, F))]
+    tx = t(x, dtype).requires_grad_(True)
+    tc, th = t(init[0][0]).requires_grad_(True), t(init[0][1], dtype).requires_grad_(True)
+    out, final = dynamic_rnn(cell, tx, sequence_length=durations, initial_state=(tc, th), time_major=True)
+    assert out.shape == (T, B, H, W, F) and final.c.shape == (B, H, W, F)
+    loss = (out.float() * t(d_out)).sum() + (final.c * t(d_fin[0][0])).sum() + (final.h.float() * t(d_fin[0][1])).sum()
+    loss.backward()
+    params = [dict(w_x=w_x, w_h=w_h, bias=bias)]
+    if dtype == torch.bfloat16:
+        r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+        x, params, init = r(x), _round_params(params), [(init[0][0], r(init[0][1]))]
+    ro, rf, caches = oc.rnn_forward(x, durations, params, init, return_cache=True)
+    close(out, ro, dtype, "outputs")
+    close(final.c, rf[0][0], dtype, "final c")
+    close(final.h, rf[0][1], dtype, "final h")
+    d_in, grads, d_init = oc.rnn_backward(caches, durations, params, d_out, d_fin)
+    close(tx.grad, d_in, dtype, "d_inputs")
+    close(cell.input_to_state_kernel.grad, grads[0]["dw_x"], dtype, "dw_x")
+    close(cell.hidden_to_state_kernel.grad, grads[0]["dw_h"], dtype, "dw_h")
+    close(cell.bias.grad, grads[0]["dbias"], dtype, "dbias")
+    close(tc.grad, d_init[0][0], dtype, "d_init c")
+    close(th.grad, d_init[0][1], dtype, "d_init h")

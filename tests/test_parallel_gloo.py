@@ -47,6 +47,26 @@ def _loss(tp, images, histories, durations, targets, P, weights, reduce):
     return rows.mean() if reduce == "mean" else rows.mean(dim=1).sum()
 
 
+def _rank_grads(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return [torch.randn(3, 4, generator=g) * 30, torch.randn(5, generator=g) * 30]
+
+
+def _adam_case(grad_sets, all_reduce):
+    """Two steps of the flat-bucket Adam (actor-critic trainer) with clip 40 on the mean of grad_sets."""
+    from imagesegmentation_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(7)
+    params = [torch.nn.Parameter(torch.randn(3, 4, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g))]
+    opt = FlatAdam(params, learning_rate=1e-2, clip_norm=40.0)
+    for _ in range(2):
+        opt.zero_grad()
+        for grads in grad_sets:
+            for p, gr in zip(params, grads):
+                p.grad += gr / len(grad_sets)
+        opt.step(all_reduce=all_reduce)
+    return torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,6 +86,7 @@ def _worker(rank, world, port, ret):
         parallel.allreduce_gradients_(flat, average=(mode == "mean"))
         out[mode] = flat.numpy()
     out["max"] = parallel.allreduce_max(float(rank + 1), "cpu")
+    out["adam"] = _adam_case([_rank_grads(rank)], all_reduce=True)
     ret[rank] = out
     dist.destroy_process_group()
 
@@ -87,6 +108,8 @@ def test_two_rank_gradients_match_single_process():
         for mode in ("mean", "episode_sum"):
             assert np.allclose(ret[rank][mode], ref[mode], rtol=1e-10, atol=1e-12), (rank, mode)
         assert ret[rank]["max"] == 2.0
+        assert np.allclose(ret[rank]["adam"], _adam_case([_rank_grads(0), _rank_grads(1)], all_reduce=False),
+                           rtol=1e-6, atol=1e-7)
 
 
 def test_shard_range_partitions_exactly():
