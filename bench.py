@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--rollouts", type=int, default=16384, help="IoU rollouts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--rl-envs", type=int, default=2048, help="REINFORCE rollouts per GPU per step (0 = skip)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -143,6 +144,38 @@ def time_kernels(model, batch, dtype_name, reps=5):
                            frac=rec["hbm_frac"])
             out.append(rec)
     return out
+
+
+def bench_reinforce(n_envs, steps, device, rank, dtype):
+    """Sampled rollouts + terminal IoU + one policy update per step: the reference's REINFORCE loop
+    (end-token 2-layer net at 28x28, at most 10 sampled steps) for n_envs lock-stepped episodes."""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl.reinforce import BatchedReinforce, ExperimentPolicyEstimator
+    ds = data.PolygonDataset.synthetic(64, image_size=28, prediction_size=28, max_timesteps=10, history_length=2,
+                                       seed=10 + rank, end_token=True)
+    policy = ExperimentPolicyEstimator(28, 28, max_timesteps=10, end_token=True, compute_dtype=dtype, device=device,
+                                       seed=0)
+    runner = BatchedReinforce(policy, ds, n_envs)
+    # the dataset's own sampler draws without replacement; n_envs episodes reuse the 64 polygons
+    rs = np.random.RandomState(20 + rank)
+    idx = rs.randint(0, len(ds), [n_envs])
+    images = ds._images[idx]
+    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
+    runner.step(images, polygons)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ep = runner.rollout(images, polygons)
+    torch.cuda.synchronize()
+    t_roll = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ep, _ = runner.step(images, polygons)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    return {"envs": n_envs, "size": 28, "max_steps": 10, "rollouts_per_s_rollout_only": n_envs / t_roll,
+            "rollouts_per_s_with_update": n_envs / t_step, "ms_per_step": t_step * 1e3,
+            "mean_reward": float(ep["reward"].mean()), "mean_length": float(ep["lengths"].float().mean())}
 
 
 def load_pmc_traffic():
@@ -320,6 +353,17 @@ def main():
         raster["rollouts_per_s"] = args.rollouts * world / raster["ms_per_launch"] * 1e3
         raster["rollouts"] = args.rollouts * world
 
+    rl = None
+    if args.rl_envs > 0:
+        rl = bench_reinforce(args.rl_envs, 3, device, rank, dtype)
+        if world > 1:
+            r = torch.tensor([rl["ms_per_step"]], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.MAX)
+            rl["ms_per_step"] = float(r.item())
+            rl["envs"] = args.rl_envs * world
+            rl["rollouts_per_s_with_update"] = rl["envs"] / rl["ms_per_step"] * 1e3
+            rl.pop("rollouts_per_s_rollout_only")
+
     kernels, roofline, cpu = None, None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = time_kernels(model, batch, args.dtype)
@@ -351,7 +395,7 @@ def main():
             (MFMA_PEAK_TFLOPS[args.dtype] * world),
             "loss": float(loss),
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
-            "iou": raster,
+            "iou": raster, "reinforce": rl,
         }
         print(json.dumps(line))
     if world > 1:
