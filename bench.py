@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--rl-envs", type=int, default=2048, help="REINFORCE rollouts per GPU per step (0 = skip)")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="keep MIOpen's immediate-mode pick for the encoder convs instead of letting it time its solvers "
+                         "during warm-up")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -296,6 +299,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
+    if not args.no_miopen_find:
+        torch.backends.cudnn.benchmark = True
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

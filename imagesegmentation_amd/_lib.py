@@ -25,12 +25,14 @@ SIGNATURES = {
     "isg_softmax_xent_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp]),
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
+    "isg_sequence_metrics": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "isg_avgpool_fwd": (_int, [_vp, _ll, _int, _int, _int, _int, _int, _vp, _vp]),
     "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                      _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
-    "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _int, _int, _int, _int, _int, _vp, _int,
-                                          _vp, _vp, _vp]),
+    "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp,
+                                          _int, _vp, _vp, _vp]),
     "isg_convlstm_dgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _int, _int, _vp,
                                   _vp]),
     "isg_convlstm_wgrad_workspace_bytes": (_ll, [_int, _int]),

@@ -235,8 +235,10 @@ class SequenceInput:
         if x_seq is not None:
             self.T, self.B, self.H, self.W, self.C = x_seq.shape
             self.hist = 0
+            self.device = x_seq.device
         else:
             self.B, self.H, self.W, cf = static.shape
+            self.device = static.device
             if hist_dense is not None:
                 self.T, self.hist = hist_dense.shape[1], hist_dense.shape[4]
             else:
@@ -289,7 +291,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
     L, T = len(cells), seq.T
     dt = cells[0].compute_dtype
     B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
-    dev = init_state[0][0].device
+    dev = seq.device
     packed = [seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
     seq.prepare(dt, packed[0].cs)
     n_keep = T + 1 if save else 2
@@ -297,8 +299,10 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
     Cs = [torch.empty([n_keep, B, H, W, F], dtype=torch.float32, device=dev) for _ in range(L)]
     Gs = [torch.empty([T, B, H, W, F, 4], dtype=dt, device=dev) for _ in range(L)] if save else None
     for l in range(L):
-        Cs[l][0].copy_(init_state[l][0])
-        Hs[l][0].copy_(init_state[l][1])
+        c0, h0 = init_state[l]
+        # None = zero state: a fill, not a copy of a zero tensor
+        Cs[l][0].zero_() if c0 is None else Cs[l][0].copy_(c0)
+        Hs[l][0].zero_() if h0 is None else Hs[l][0].copy_(h0)
     out = torch.zeros([B, T, H, W, F], dtype=dt, device=dev)
     cur = 0
     for t in range(t_run):
@@ -320,7 +324,7 @@ class _SequenceFunction(torch.autograd.Function):
     hand-written reverse sweep (pointwise, weight-gradient and data-gradient kernels) backward."""
 
     @staticmethod
-    def forward(ctx, multi, seq, durations_dev, t_run, n_state, *tensors):
+    def forward(ctx, multi, seq, durations_dev, t_run, pool, *tensors):
         # tensors = [layer-0 differentiable input] + [c0, h0] * L + [w_x, w_h, bias] * L
         cells = list(multi.cells)
         L = len(cells)
@@ -329,10 +333,15 @@ class _SequenceFunction(torch.autograd.Function):
         ctx.multi, ctx.seq, ctx.durations_dev, ctx.t_run = multi, seq, durations_dev, t_run
         ctx.saved = (Hs, Cs, Gs, packed)
         ctx.in_dtype = tensors[0].dtype
-        ctx.state_dtypes = [(c.dtype, h.dtype) for c, h in init_state]
+        ctx.pool = pool
+        if pool > 1:  # the caller only wants the k x k window means of the emitted outputs
+            out = ops.avgpool(out, pool)
+        ctx.state_dtypes = [(None if c is None else c.dtype, None if h is None else h.dtype) for c, h in init_state]
+        # unused outputs (normally the final state) arrive as None in backward instead of zero tensors
+        ctx.set_materialize_grads(False)
         flat = [out]
-        for c, h in final:
-            flat += [c.clone(), h.clone()]
+        for c, h in final:  # views of the saved state buffers: do not modify them in place
+            flat += [c, h]
         return tuple(flat)
 
     @staticmethod
@@ -344,7 +353,9 @@ class _SequenceFunction(torch.autograd.Function):
         dt = cells[0].compute_dtype
         B, H, W, F, T = seq.B, seq.H, seq.W, cells[0]._filters, seq.T
         dev = Hs[0].device
-        d_out = d_out.to(dt).contiguous() if d_out is not None else torch.zeros([B, T, H, W, F], dtype=dt, device=dev)
+        pool = ctx.pool
+        d_out = d_out.to(dt).contiguous() if d_out is not None else \
+            torch.zeros([B, T, H // pool, W // pool, F], dtype=dt, device=dev)
         dc_state, dh_state = [], []
         for l in range(L):
             dc, dh = d_final[2 * l], d_final[2 * l + 1]
@@ -375,11 +386,11 @@ class _SequenceFunction(torch.autograd.Function):
             for l in reversed(range(L)):
                 x_in = x0 if l == 0 else Hs[l - 1][t + 1]
                 if l == L - 1:
-                    above, stride = d_out[:, t], T * H * W * F
+                    above, stride, k = d_out[:, t], T * (H // pool) * (W // pool) * F, pool
                 else:
-                    above, stride = dx_mid, H * W * F
+                    above, stride, k = dx_mid, H * W * F, 1
                 ops.pointwise_bwd(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l],
-                                  durations_dev, t, dy=dy, dc_prev=dc_state[l])
+                                  durations_dev, t, dy=dy, dc_prev=dc_state[l], pool=k)
                 ops.wgrad(x_in, Hs[l][t], dy, packed[l].c, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t,
                           hist_points=seq.points(t) if l == 0 else None, hist=packed[l].hist,
                           mode=ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST, workspace=slabs[l])
@@ -403,7 +414,7 @@ class _SequenceFunction(torch.autograd.Function):
         result = [None, None, None, None, None, d_input]
         for l in range(L):
             cd, hd = ctx.state_dtypes[l]
-            result += [dc_state[l].to(cd), dh_state[l].to(hd)]
+            result += [None if cd is None else dc_state[l].to(cd), None if hd is None else dh_state[l].to(hd)]
         for l in range(L):
             result += list(grads[l])
         return tuple(result)
@@ -433,13 +444,15 @@ def _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state):
     return torch.stack(outs, dim=1), tuple(state)
 
 
-def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True):
+def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True, output_pool=1):
     """``tf.nn.dynamic_rnn`` for a ``MultiRNNCell`` (or a single cell) of ConvLSTM cells.
 
     inputs: a time-major tensor [T, B, H, W, C] (``time_major=False``: [B, T, H, W, C]) or a
     ``SequenceInput``.  sequence_length: int array/tensor [B] or None.  Past a sample's length the
     emitted output is zero and its state is carried through unchanged.
     Returns (outputs, final_state); outputs are [T, B, H, W, F] when time_major else [B, T, H, W, F].
+    ``output_pool`` = k > 1 (not in TensorFlow): the outputs come back averaged over k x k windows,
+    [.., H/k, W/k, F], and the pool's gradient is applied inside the recurrence's backward sweep.
     """
     multi = cell if isinstance(cell, MultiRNNCell) else MultiRNNCell([cell])
     if isinstance(inputs, SequenceInput):
@@ -465,11 +478,15 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
             t_run = int(host.max()) if host.size else 0
             durations_dev = torch.as_tensor(host.astype(np.int32), device=dev)
         t_run = max(0, min(t_run, T))
+    wide = any(c._filters != ops.F_HIDDEN for c in multi.cells)
     if initial_state is None:
-        initial_state = multi.zero_state(B, dev)
+        # the fused node takes "no tensor" as the zero state
+        initial_state = multi.zero_state(B, dev) if wide else tuple((None, None) for _ in multi.cells)
     elif not isinstance(initial_state[0], (tuple, list)):
         initial_state = (initial_state,)
-    if any(c._filters != ops.F_HIDDEN for c in multi.cells):
+    if wide:
+        if output_pool != 1:
+            raise NotImplementedError("output_pool is for 16-filter cells")
         out, final = _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state)
         if time_major:
             out = out.transpose(0, 1)
@@ -479,7 +496,7 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
         tensors += [c, h]
     for c in multi.cells:
         tensors += [c.input_to_state_kernel, c.hidden_to_state_kernel, c.bias]
-    flat = _SequenceFunction.apply(multi, seq, durations_dev, t_run, len(multi.cells), *tensors)
+    flat = _SequenceFunction.apply(multi, seq, durations_dev, t_run, int(output_pool), *tensors)
     out = flat[0]
     final = tuple(LSTMStateTuple(flat[1 + 2 * l], flat[2 + 2 * l]) for l in range(len(multi.cells)))
     if time_major:

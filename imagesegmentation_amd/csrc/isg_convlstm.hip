@@ -227,6 +227,8 @@ struct PointwiseParams {
     const float* c_cur;    // [B,H,W,F]
     const void* dh_above;  // grad of h as the layer's OUTPUT, sample stride dh_above_bstride, or null
     long long dh_above_bstride;
+    int pool;              // > 1: dh_above is on the grid pooled by pool x pool windows (gradient of an average pool)
+    int W;
     const void* dh_state;  // grad of h as carried STATE [B,H,W,F], or null
     const float* dc_state; // [B,H,W,F] or null
     float* dc_prev;        // [B,H,W,F] (may alias dc_state)
@@ -285,11 +287,25 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams
             float dh[CPT], cpv[CPT], ccv[CPT];
             const T* above = static_cast<const T*>(p.dh_above);
             const T* state = static_cast<const T*>(p.dh_state);
-            const size_t ao = (size_t)b * p.dh_above_bstride + (size_t)(pixel - (long long)b * p.HW) * F_ + q * CPT;
+            const int pix = (int)(pixel - (long long)b * p.HW);
+            size_t ao = (size_t)b * p.dh_above_bstride + q * CPT;
+            if (p.pool > 1) {
+                const int y = pix / p.W, x = pix - y * p.W;
+                ao += ((size_t)(y / p.pool) * (p.W / p.pool) + x / p.pool) * F_;
+            } else {
+                ao += (size_t)pix * F_;
+            }
             float da[CPT], ds[CPT];
 #pragma unroll
             for (int k = 0; k < CPT; ++k) da[k] = 0.0f, ds[k] = 0.0f;
-            if (above) load_run<CPT>(above + ao, da);
+            if (above) {
+                load_run<CPT>(above + ao, da);
+                if (p.pool > 1) {
+                    const float inv = 1.0f / (float)(p.pool * p.pool);
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) da[k] *= inv;
+                }
+            }
             if (state) load_run<CPT>(state + so, ds);
             load_run<CPT>(p.c_prev + so, cpv);
             load_run<CPT>(p.c_cur + so, ccv);
@@ -679,7 +695,7 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const fl
 }
 
 extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur,
-                                          const void* dh_above, long long dh_above_batch_stride,
+                                          const void* dh_above, long long dh_above_batch_stride, int dh_above_pool,
                                           const void* dh_state, const float* dc_state, int B, int H, int W, int F,
                                           int dtype, const int32_t* durations, int t, void* dy, float* dc_prev,
                                           void* stream) {
@@ -688,7 +704,9 @@ extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev
     ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_convlstm_pointwise_bwd: dtype %d", dtype);
     PointwiseParams p = {};
     p.gates = gates, p.c_prev = c_prev, p.c_cur = c_cur;
-    p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride;
+    ISG_REQUIRE(dh_above_pool >= 1 && H % dh_above_pool == 0 && W % dh_above_pool == 0, ISG_EINVAL,
+                "isg_convlstm_pointwise_bwd: pool %d must divide the %dx%d grid", dh_above_pool, H, W);
+    p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool = dh_above_pool, p.W = W;
     p.dh_state = dh_state, p.dc_state = dc_state, p.dc_prev = dc_prev, p.dy = dy;
     p.durations = durations, p.t = t, p.B = B, p.HW = H * W;
     const long long total = (long long)B * H * W * (dtype == ISG_F32 ? F_ : F_ / 2);

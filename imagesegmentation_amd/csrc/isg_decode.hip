@@ -149,6 +149,45 @@ int check_rows(const char* who, int rows, int cols, int dtype) {
     return ISG_OK;
 }
 
+
+// Masked sequence metrics in one launch of one workgroup (rows = B*T is a few hundred to a few
+// thousand): out = {#(pred == class(target) and t < duration), sum of masked L2 errors,
+// max of masked L2 errors, sum of durations}, all double.
+__global__ __launch_bounds__(256) void sequence_metrics_kernel(const int* __restrict__ pred,
+                                                              const int* __restrict__ targets,
+                                                              const int* __restrict__ durations, int B, int T, int P,
+                                                              double* __restrict__ out) {
+    __shared__ double red[3][256];
+    double correct = 0.0, esum = 0.0, emax = 0.0;
+    for (int r = threadIdx.x; r < B * T; r += 256) {
+        const int b = r / T, t = r - b * T;
+        const bool live = t < durations[b];
+        const int tx = targets[2 * r], ty = targets[2 * r + 1];
+        const int a = pred[r];
+        const int ax = a / P, ay = a - ax * P;
+        if (live && a == tx * P + ty) correct += 1.0;
+        const double dx = (double)(tx - ax), dy = (double)(ty - ay);
+        const double e = live ? sqrt(dx * dx + dy * dy) : 0.0;
+        esum += e;
+        emax = fmax(emax, e);
+    }
+    red[0][threadIdx.x] = correct, red[1][threadIdx.x] = esum, red[2][threadIdx.x] = emax;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+            red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long num = 0;
+        for (int b = 0; b < B; ++b) num += durations[b];
+        out[0] = red[0][0], out[1] = red[1][0], out[2] = red[2][0], out[3] = (double)num;
+    }
+}
+
 }  // namespace
 
 extern "C" int isg_softmax_xent_fwd(const void* logits, const int32_t* labels, const float* weights, int rows,
@@ -209,4 +248,14 @@ extern "C" int isg_sample_rows(const void* logits, int rows, int cols, int dtype
         hipLaunchKernelGGL(sample_kernel<__hip_bfloat16>, grid, block, 0, s,
                            static_cast<const __hip_bfloat16*>(logits), rows, cols, seed, row_offset, out_idx);
     return isg::check_launch("sample_kernel");
+}
+
+extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T,
+                                    int P, double* out4, void* stream) {
+    ISG_REQUIRE(B >= 0 && T >= 0 && P >= 1, ISG_EINVAL, "isg_sequence_metrics: bad shape B=%d T=%d P=%d", B, T, P);
+    ISG_REQUIRE(out4 && (B * T == 0 || (pred && targets && durations)), ISG_EINVAL,
+                "isg_sequence_metrics: null pointer");
+    hipLaunchKernelGGL(sequence_metrics_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), pred, targets,
+                       durations, B, T, P, out4);
+    return isg::check_launch("sequence_metrics_kernel");
 }

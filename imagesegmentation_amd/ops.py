@@ -99,14 +99,16 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
 
 
 def pointwise_bwd(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, durations=None, t=0,
-                  dy=None, dc_prev=None):
-    """Gate backward. Returns (dy [B,H,W,F,4], dc_prev float32 [B,H,W,F])."""
+                  dy=None, dc_prev=None, pool=1):
+    """Gate backward. Returns (dy [B,H,W,F,4], dc_prev float32 [B,H,W,F]).  ``pool`` = k > 1: dh_above is
+    the gradient of the k x k average-pooled output, [H/k, W/k, F] per sample."""
     B, H, W, F, _ = gates.shape
     dy = torch.empty_like(gates) if dy is None else dy
     dc_prev = torch.empty([B, H, W, F], dtype=torch.float32, device=gates.device) if dc_prev is None else dc_prev
     rc = _lib.lib().isg_convlstm_pointwise_bwd(
         _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(c_cur), dh_above.data_ptr() if dh_above is not None else None,
-        int(dh_above_batch_stride), _lib.ptr(dh_state), _lib.ptr(dc_state), B, H, W, F, dtype_code(gates.dtype),
+        int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), B, H, W, F,
+        dtype_code(gates.dtype),
         _lib.ptr(durations), int(t), _lib.ptr(dy), _lib.ptr(dc_prev), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_pointwise_bwd")
     return dy, dc_prev
@@ -172,3 +174,16 @@ def wgrad_finish(workspace, shape, c_real, hist, dw_x, dw_h, dbias, accumulate=F
                                               dw_h.shape[2], int(bool(accumulate)), _lib.ptr(dw_x), _lib.ptr(dw_h),
                                               _lib.ptr(dbias), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_wgrad_finish")
+
+
+def avgpool(x, k):
+    """Mean over k x k windows of a contiguous NHWC tensor [..., H, W, F] -> [..., H/k, W/k, F]."""
+    _need_cuda(x, "x")
+    assert x.is_contiguous()
+    H, W, F = x.shape[-3:]
+    n = x.numel() // (H * W * F)
+    out = torch.empty(tuple(x.shape[:-3]) + (H // k, W // k, F), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().isg_avgpool_fwd(_lib.ptr(x), n, H, W, F, int(k), dtype_code(x.dtype), _lib.ptr(out),
+                                    _lib.current_stream())
+    _lib.check(rc, "isg_avgpool_fwd")
+    return out

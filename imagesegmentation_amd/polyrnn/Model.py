@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import parallel, util
+from .. import ops, parallel, util
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, SequenceInput, _run_sequence_forward, dynamic_rnn
 from . import decode
 
@@ -54,6 +54,21 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     w = w_hwio.to(dtype).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
     y = F.relu(F.conv2d(x, w, b.to(dtype), padding=pad))
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+class _AvgPool(torch.autograd.Function):
+    """k x k mean over the grid of [..., P, P, F] (isg_avgpool_fwd); the gradient spreads evenly."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return ops.avgpool(x, k)
+
+    @staticmethod
+    def backward(ctx, d):
+        k = ctx.k
+        d = d / (k * k)
+        return d.repeat_interleave(k, dim=-3).repeat_interleave(k, dim=-2), None
 
 
 class Model:
@@ -183,11 +198,10 @@ class Model:
 
     def head(self, rnn_out):
         """rnn_out [B,T,P,P,F] -> logits [B,T,K] (reference History2LargeExperiment.py:48-50)."""
-        B, T, P = rnn_out.shape[0], rnn_out.shape[1], rnn_out.shape[2]
+        B, T, P = rnn_out.shape[0], rnn_out.shape[1], self.prediction_size
         hs = self.head_size
-        if hs != P:
-            k = P // hs
-            rnn_out = rnn_out.reshape(B, T, hs, k, hs, k, -1).float().mean(dim=(3, 5)).to(self.compute_dtype)
+        if hs != P and rnn_out.shape[2] != hs:  # not pooled by the recurrence itself
+            rnn_out = _AvgPool.apply(rnn_out.contiguous(), P // hs)
         flat = rnn_out.reshape(B * T, hs * hs * self.rnn_filters)
         logits = torch.addmm(self.dense_bias.to(flat.dtype), flat, self.dense_kernel.to(flat.dtype))
         return logits.reshape(B, T, self.num_classes)
@@ -195,8 +209,9 @@ class Model:
     def forward(self, images, durations, histories, initial_state=None):
         features = self.encode(images)
         seq = self._sequence_input(features, histories)
+        # the head's average pool rides inside the recurrence node: its gradient is never materialised
         rnn_out, final = dynamic_rnn(self.rnn, seq, sequence_length=durations, initial_state=initial_state,
-                                     time_major=False)
+                                     time_major=False, output_pool=self.prediction_size // self.head_size)
         self.rnn_final_state = final
         self.prediction_logits = self.head(rnn_out)
         return self.prediction_logits, final
@@ -207,19 +222,15 @@ class Model:
         return decode.prediction_max(self.prediction_logits, self.head_size)
 
     def _loss_and_metrics(self, logits, durations, targets):
-        targets = self._to_dev(targets, torch.int64)
-        dur = self._to_dev(durations, torch.int64)
+        targets = self._to_dev(targets, torch.int32)
+        dur = self._to_dev(durations, torch.int32)
         B, T, K = logits.shape
         dense = targets[..., 0] * self.head_size + targets[..., 1]  # x-major (Model.py:39)
-        loss = decode.softmax_xent_mean(logits, dense)
+        pred = torch.empty([B * T], dtype=torch.int32, device=self.device)
+        loss = decode.softmax_xent_mean(logits, dense, argmax_out=pred)
         with torch.no_grad():
-            pred = decode.argmax_rows(logits)
-            mask = torch.arange(T, device=self.device)[None, :] < dur[:, None]
-            num = dur.sum()
-            acc = ((pred == dense) & mask).sum().double() / num
-            pm = torch.stack([pred // self.head_size, pred % self.head_size], dim=2)
-            err = (targets - pm).double().norm(dim=2) * mask.double()
-            metrics = dict(loss=loss.detach(), accuracy=acc, avg_error=err.sum() / num.double(), max_error=err.max())
+            m = decode.sequence_metrics(pred, targets, dur, self.head_size)
+            metrics = dict(loss=loss.detach(), accuracy=m[0] / m[3], avg_error=m[1] / m[3], max_error=m[2])
         return loss, metrics
 
     # -- optimiser (reference Model.py:106-112) --------------------------------------------------

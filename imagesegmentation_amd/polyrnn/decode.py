@@ -16,14 +16,15 @@ def _rows(logits):
 
 class _XentRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, weights):
+    def forward(ctx, logits, labels, weights, argmax_out=None):
         z, rows, cols = _rows(logits)
         lab = labels.reshape(-1).to(torch.int32).contiguous()
         w = weights.reshape(-1).to(torch.float32).contiguous() if weights is not None else None
         loss = torch.empty([rows], dtype=torch.float32, device=z.device)
         lse = torch.empty([rows], dtype=torch.float32, device=z.device)
         rc = _lib.lib().isg_softmax_xent_fwd(_lib.ptr(z), _lib.ptr(lab), _lib.ptr(w), rows, cols, dtype_code(z.dtype),
-                                             _lib.ptr(loss), _lib.ptr(lse), None, _lib.current_stream())
+                                             _lib.ptr(loss), _lib.ptr(lse), _lib.ptr(argmax_out),
+                                             _lib.current_stream())
         _lib.check(rc, "isg_softmax_xent_fwd")
         ctx.save_for_backward(z, lab, lse, w)
         ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
@@ -41,17 +42,33 @@ class _XentRows(torch.autograd.Function):
         rc = _lib.lib().isg_softmax_xent_bwd(_lib.ptr(z), _lib.ptr(lab), _lib.ptr(lse), _lib.ptr(scale), 1.0, rows,
                                              cols, dtype_code(z.dtype), _lib.ptr(dz), _lib.current_stream())
         _lib.check(rc, "isg_softmax_xent_bwd")
-        return dz.reshape(ctx.shape).to(ctx.in_dtype), None, None
+        return dz.reshape(ctx.shape).to(ctx.in_dtype), None, None, None
 
 
-def softmax_xent_rows(logits, labels, weights=None):
-    """Per-row sparse softmax cross-entropy (optionally times a per-row weight)."""
-    return _XentRows.apply(logits, labels, weights)
+def softmax_xent_rows(logits, labels, weights=None, argmax_out=None):
+    """Per-row sparse softmax cross-entropy (optionally times a per-row weight).  ``argmax_out``
+    (int32, one per row) receives the first-maximum class of each row from the same pass."""
+    return _XentRows.apply(logits, labels, weights, argmax_out)
 
 
-def softmax_xent_mean(logits, labels, weights=None):
+def softmax_xent_mean(logits, labels, weights=None, argmax_out=None):
     """mean over every row (reference polyrnn/Model.py:98-100)."""
-    return softmax_xent_rows(logits, labels, weights).mean()
+    return softmax_xent_rows(logits, labels, weights, argmax_out).mean()
+
+
+def sequence_metrics(pred, targets, durations, prediction_size):
+    """Masked accuracy / mean L2 error / max L2 error of reference polyrnn/Model.py:44-54 from ONE kernel:
+    pred int32 [B, T] argmax classes, targets int [B, T, 2] (x, y), durations int [B].
+    Returns a float64 device tensor [4] = (correct, error sum, error max, number of live steps)."""
+    B, T = targets.shape[0], targets.shape[1]
+    pred = pred.reshape(-1).to(torch.int32).contiguous()
+    tg = targets.to(torch.int32).contiguous()
+    dur = durations.to(torch.int32).contiguous()
+    out = torch.empty([4], dtype=torch.float64, device=pred.device)
+    rc = _lib.lib().isg_sequence_metrics(_lib.ptr(pred), _lib.ptr(tg), _lib.ptr(dur), B, T, int(prediction_size),
+                                         _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_sequence_metrics")
+    return out
 
 
 def argmax_rows(logits):

@@ -125,11 +125,14 @@ int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev
 /* Backward, step 1 (pointwise): from dL/dh (= dh_above as emitted output + dh_state as carried
  * state, either may be NULL) and dL/dc (dc_state, may be NULL) to the pre-activation gradient
  * dy [B][H][W][F][4] and dc_prev (may alias dc_state).  Replaces the gradient of
- * reference convLSTM.py:40-43 that tf.gradients derives (reference polyrnn/Model.py:108). */
+ * reference convLSTM.py:40-43 that tf.gradients derives (reference polyrnn/Model.py:108).
+ * dh_above_pool = 1: dh_above is [H][W][F] per sample.  dh_above_pool = k > 1: the emitted output went
+ * through a k x k average pool (isg_avgpool_fwd) and dh_above is the gradient of the POOLED tensor,
+ * [H/k][W/k][F] per sample; each pixel takes 1/k^2 of its window's value, never materialised. */
 int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
-                               long long dh_above_batch_stride, const void* dh_state, const float* dc_state, int B,
-                               int H, int W, int F, int dtype, const int32_t* durations, int t, void* dy,
-                               float* dc_prev, void* stream);
+                               long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                               const float* dc_state, int B, int H, int W, int F, int dtype,
+                               const int32_t* durations, int t, void* dy, float* dc_prev, void* stream);
 
 /* Backward, step 2 (data gradient of reference convLSTM.py:36-37): dx (optional; first
  * dx_channels channels, pixel stride dx_channel_stride, += when dx_accumulate) and dh_prev
@@ -180,6 +183,24 @@ int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, const float*
 int isg_argmax_rows(const void* logits, int rows, int cols, int dtype, int32_t* out_idx, void* stream);
 int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
                     unsigned long long row_offset, int32_t* out_idx, void* stream);
+
+/* Masked metrics of reference polyrnn/Model.py:44-54 in one launch: pred int32 [B*T] (argmax class),
+ * targets int32 [B][T][2] (x, y), durations int32 [B], P = side of the class grid (class = x*P + y;
+ * the end token (P, 0) is class P*P).  out4 (device, double): {number of steps with t < duration and
+ * pred == class(target); sum over those steps of ||target - (pred / P, pred % P)||_2; the maximum of
+ * the same (0 for masked steps); sum of durations}.  accuracy = out4[0] / out4[3],
+ * avg_error = out4[1] / out4[3], max_error = out4[2]. */
+int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T, int P,
+                         double* out4, void* stream);
+
+/* ---- head pooling ----------------------------------------------------------------------------
+ * Mean over non-overlapping k x k windows of x [N][H][W][F] -> out [N][H/k][W/k][F], same dtype,
+ * float accumulation.  The reference feeds the recurrent output straight into
+ * dense(P*P*16 -> P*P) (polyrnn/History2LargeExperiment.py:48-50), which has 4e10 weights at P = 224; this
+ * pool puts the head on a coarser grid and has no counterpart in the reference.  k a power of two,
+ * F a multiple of 8 (bf16) / 4 (float) with k * F / that <= 64.  Its gradient is folded into
+ * isg_convlstm_pointwise_bwd (dh_above_pool). */
+int isg_avgpool_fwd(const void* x, long long N, int H, int W, int F, int k, int dtype, void* out, void* stream);
 
 #ifdef __cplusplus
 }
