@@ -9,6 +9,8 @@
 // other.  Staging is split: the global loads of the next tile are issued BEFORE the epilogue and
 // their LDS writes come after it, which keeps ~40 KB per CU in flight during the gate math.
 // The k-loop is fully unrolled with the next step's fragments read while the current MFMAs issue.
+#include <utility>
+
 #include "isg_convlstm_shared.h"
 
 using namespace isgc;
@@ -417,18 +419,36 @@ namespace {
 template <int C0, int MT>
 struct WG {
     static constexpr int CPT = C0 + F_;
-    static constexpr int NCH0 = C0 / 8, NCH = CPT / 8;
-    static constexpr int PSTRIDE = CPT * 2 + 16;
-    static constexpr int DSTRIDE = NG * 2 + 16;
-    static constexpr int IN_BYTES = (NPX * PSTRIDE + 15) & ~15;
-    static constexpr int DY_BYTES = TH * TW * DSTRIDE;
+    static constexpr int NCH0 = C0 / 8;  // 16-byte chunks per pixel of x; h_prev has 2, dY has 8
+    // LDS images are split into regions of 32 channels (64 bytes) per pixel with NO padding: one
+    // transposing read of a 32-lane phase then covers 4 consecutive pixels x 64 bytes = 256
+    // contiguous bytes, i.e. every bank once.  (A padded [pixel][all channels] image makes the four
+    // pixels' 16-bank windows overlap: 2-way conflicts on most reads.)
+    static constexpr int RSTRIDE = 64;
+    static constexpr int IN_REGION = NPX * RSTRIDE;            // one 32-channel row tile of [x | h_prev]
+    static constexpr int DY_REGION = TH * TW * RSTRIDE + 128;  // one 32-column half of dY; +128 B puts the two
+                                                               // halves of a pixel on different banks for the stores
+    static constexpr int IN_BYTES = MT * IN_REGION;
+    static constexpr int DY_BYTES = 2 * DY_REGION;
     static constexpr int BUF_BYTES = IN_BYTES + DY_BYTES;
-    static constexpr int NCHUNK = NPX * NCH + TH * TW * 8;  // 16-byte chunks per tile (input halo + dY)
-    static constexpr int NLOAD = (NCHUNK + kPPThreads - 1) / kPPThreads;
-    static constexpr int NSLOT = MT == 2 ? 5 : 3;
+    // Staging enumerates x chunks, then h_prev chunks, then dY chunks, each range rounded up to a
+    // whole number of 512-thread passes so that the kind of chunk is a compile-time fact per pass.
+    static constexpr int N0 = NPX * NCH0, N1 = NPX * 2, N2 = TH * TW * 8;
+    static constexpr int J0 = (N0 + kPPThreads - 1) / kPPThreads, J1 = (N1 + kPPThreads - 1) / kPPThreads,
+                         J2 = N2 / kPPThreads;
+    static constexpr int NLOAD = J0 + J1 + J2;
+    static constexpr int NSLOT = MT == 2 ? 5 : 3;  // taps per wave
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static_assert(CPT <= MT * 32, "row tiles must cover the input channels");
+    static_assert(N2 % kPPThreads == 0, "dY tile must fill whole passes");
+    static_assert(BUF_BYTES < (1 << 20), "LDS offsets are packed into 20 bits");
 };
 
+// Work split of the 8 waves.  The pixel (reduction) axis is cut in two: waves with kh = 0 reduce
+// the left 16 pixels of every tile row, kh = 1 the right 16, and a wave keeps BOTH 32-column halves
+// of dY for its taps, so a k-step costs it (taps + 2) operand fragments for 2 * taps MFMAs - the
+// loop is bound by LDS reads, and this split needs 40 % fewer of them than one column half per wave.
+// The two kh partners are summed through LDS once, after the last tile.
 template <int C0, int MT>
 __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p) {
     using K = WG<C0, MT>;
@@ -438,67 +458,118 @@ __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    // which output tiles this wave owns
-    int mt, nt, tap0, ntaps;
+    const int kh = wave & 1;
+    int mt, tap0, ntaps;
     if constexpr (MT == 2) {
-        mt = (wave >> 1) & 1, nt = wave & 1, tap0 = (wave >> 2) * 5, ntaps = (wave >> 2) ? 4 : 5;
+        // waves w and w + 4 share a SIMD: one takes 5 taps, the other 4
+        mt = (wave >> 1) & 1, tap0 = (wave >> 2) * 5, ntaps = (wave >> 2) ? 4 : 5;
     } else {
-        const int q = wave >> 1;
-        mt = 0, nt = wave & 1, tap0 = q == 0 ? 0 : 2 * q + 1, ntaps = q == 0 ? 3 : 2;
+        const int g = wave >> 1;  // tap groups {0,1,2} {3,4} {5,6} {7,8}
+        mt = 0, tap0 = g == 0 ? 0 : 2 * g + 1, ntaps = g == 0 ? 3 : 2;
     }
     const bool does_bias = wave < 2;
 
-    f32x16 acc[K::NSLOT];
+    f32x16 acc[K::NSLOT][2];
 #pragma unroll
     for (int i = 0; i < K::NSLOT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    float bsum = 0.0f;
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.0f;
+    float bsum[2] = {0.0f, 0.0f};
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ntiles = tiles_per_img * p.B;
     const int n_iter = (ntiles + gridDim.x - 1) / gridDim.x;
 
+    // ---- per-thread facts about its chunk of every staging pass, fixed for the whole kernel ----
+    // info = byte offset inside an LDS buffer | hy << 20 | hx << 24 (tile-relative row / column of the
+    // chunk's pixel, halo included); negative = this thread has no chunk in the pass
+    int info[K::NLOAD];
+#pragma unroll
+    for (int j = 0; j < K::NLOAD; ++j) {
+        int hy, hx, ldso;
+        bool has = true;
+        if (j < K::J0 + K::J1) {
+            const bool is_x = j < K::J0;
+            const int i = tid + kPPThreads * (is_x ? j : j - K::J0);
+            const int nch = is_x ? K::NCH0 : 2;
+            const int px = i / nch, ch = i - px * nch;
+            hy = px / HALO_W, hx = px - hy * HALO_W;
+            has = i < (is_x ? K::N0 : K::N1);
+            const int cbyte = ((is_x ? 0 : C0) + ch * 8) * 2;  // byte position in the [x | h_prev] channel row
+            ldso = (cbyte / K::RSTRIDE) * K::IN_REGION + px * K::RSTRIDE + (cbyte % K::RSTRIDE);
+        } else {
+            const int i = tid + kPPThreads * (j - K::J0 - K::J1);
+            const int px = i >> 3, ch = i & 7;
+            hy = px / TW + 1, hx = (px & (TW - 1)) + 1;  // same convention as the halo image: +1 = tile interior
+            ldso = K::IN_BYTES + (ch >> 2) * K::DY_REGION + px * K::RSTRIDE + (ch & 3) * 16;
+        }
+        info[j] = has ? (ldso | (hy << 20) | (hx << 24)) : -1;
+    }
+    // Element offset of pass j's chunk from the tile's first pixel, rebuilt from info at every use (one
+    // register per pass would push the accumulators into scratch): pixel offset * channels + the
+    // chunk's channel offset, which is its byte position in the 64-byte LDS pixel row.
+    auto rel_of = [&](int j) -> int {
+        int inf = info[j];
+        asm volatile("" : "+v"(inf));  // not loop-invariant as far as the compiler can tell: no hoisting
+        const int hy = (inf >> 20) & 15, hx = (inf >> 24) & 63;
+        const int pix = (hy - 1) * p.W + (hx - 1);
+        const int chb = inf & 63;
+        if (j < K::J0) return pix * C0 + (chb >> 1);  // x fills region 0 from byte 0 (C0 <= 32)
+        if (j < K::J0 + K::J1) return pix * F_ + ((chb - (C0 * 2) % K::RSTRIDE) >> 1);
+        return pix * NG + (chb >> 1) + 32 * (((inf & 0xfffff) - K::IN_BYTES) / K::DY_REGION);
+    };
+    static_assert(C0 <= 32, "x must fit the first 64-byte region");
+
     uint4 st[K::NLOAD];
     int st_dur = 0x7fffffff;
     unsigned st_inside = 0u;
-    auto stage_load = [&](int k) {
+    // All passes of the next tile are requested before the k-loop.  (Issuing them one per tile row from
+    // inside the k-loop was measured: the waves then stall on the memory queues between MFMAs and the
+    // loop takes twice as long.)
+    bool ld_valid = false, ld_interior = false;
+    int ld_ty0 = 0, ld_tx0 = 0;
+    const T *base0 = nullptr, *base1 = nullptr, *base2 = nullptr;
+    auto load_begin = [&](int k) {
         const int tile = k * gridDim.x + blockIdx.x;
-        if (k >= n_iter || tile >= ntiles) return;
+        ld_valid = k < n_iter && tile < ntiles;
+        if (!ld_valid) return;
         const int b = tile / tiles_per_img;
         const int rem = tile - b * tiles_per_img;
         const int tyi = rem / p.tiles_x;
-        const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+        ld_ty0 = tyi * TH, ld_tx0 = (rem - tyi * p.tiles_x) * TW;
         st_dur = 0x7fffffff;
         if (p.durations != nullptr) st_dur = p.durations[b];
-        st_inside = 0u;
-        int g = tid;
-        asm volatile("" : "+v"(g));
-#pragma unroll
-        for (int j = 0; j < K::NLOAD; ++j) {
-            const int idx = min(g + kPPThreads * j, K::NCHUNK - 1);
-            const T* src;
-            bool inside;
-            if (idx < NPX * K::NCH) {
-                const int px = idx / K::NCH, ch = idx - px * K::NCH;
-                const int hy = px / HALO_W, hx = px - hy * HALO_W;
-                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-                inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-                const size_t pixel = ((size_t)b * p.H + cy) * p.W + cx;
-                src = ch < K::NCH0 ? static_cast<const T*>(p.in0) + pixel * C0 + ch * 8
-                                   : static_cast<const T*>(p.in1) + pixel * F_ + (ch - K::NCH0) * 8;
+        const int origin = (b * p.H + ld_ty0) * p.W + ld_tx0;  // the host keeps B * H * W * 64 below 2^31
+        base0 = static_cast<const T*>(p.in0) + (size_t)origin * C0;
+        base1 = static_cast<const T*>(p.in1) + (size_t)origin * F_;
+        base2 = static_cast<const T*>(p.dy) + (size_t)origin * NG;
+        ld_interior = ld_ty0 >= 1 && ld_ty0 + TH + 1 <= p.H && ld_tx0 >= 1 && ld_tx0 + TW + 1 <= p.W;
+        st_inside = ld_interior ? 0xffffffffu : 0u;
+    };
+    auto load_pass = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < K::NLOAD) {
+            if (!ld_valid) return;
+            const T* base = j < K::J0 ? base0 : (j < K::J0 + K::J1 ? base1 : base2);
+            if (ld_interior) {
+                // a thread without a chunk in this pass re-reads the tile's first chunk (in bounds), value dropped
+                st[j] = *reinterpret_cast<const uint4*>(base + (info[j] >= 0 ? rel_of(j) : 0));
             } else {
-                const int d = idx - NPX * K::NCH;
-                const int px = d >> 3, ch = d & 7;
-                const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
-                inside = gy < p.H && gx < p.W;
-                const int cy = min(gy, p.H - 1), cx = min(gx, p.W - 1);
-                src = static_cast<const T*>(p.dy) + (((size_t)b * p.H + cy) * p.W + cx) * NG + ch * 8;
+                const int hy = (info[j] >> 20) & 15, hx = (info[j] >> 24) & 63;
+                const int gy = ld_ty0 + hy - 1, gx = ld_tx0 + hx - 1;
+                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && info[j] >= 0;
+                if (inside) st_inside |= 1u << j;
+                st[j] = *reinterpret_cast<const uint4*>(base + (inside ? rel_of(j) : 0));
             }
-            if (inside) st_inside |= 1u << j;
-            st[j] = *reinterpret_cast<const uint4*>(src);
         }
+    };
+    auto load_rest = [&](auto jc) {  // passes jc .. NLOAD-1
+        constexpr int j0 = decltype(jc)::value;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (load_pass(std::integral_constant<int, j0 + I>{}), ...);
+        }(std::make_integer_sequence<int, (K::NLOAD > j0 ? K::NLOAD - j0 : 0)>{});
     };
     // returns whether the staged tile takes part (its sample is still running at step t)
     auto stage_store = [&](int k, char* buf) -> bool {
@@ -506,73 +577,125 @@ __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p
         if (k >= n_iter || tile >= ntiles) return false;
         const bool live = p.t < __builtin_amdgcn_readfirstlane(st_dur);
         if (!live) return false;
-        int g = tid;
-        asm volatile("" : "+v"(g));
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const int idx = g + kPPThreads * j;
             const bool in = (st_inside >> j) & 1u;
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
-            if (idx < NPX * K::NCH) {
-                const int px = idx / K::NCH, ch = idx - px * K::NCH;
-                *reinterpret_cast<uint4*>(buf + px * K::PSTRIDE + ch * 16) = v;
-            } else if (idx < K::NCHUNK) {
-                const int d = idx - NPX * K::NCH;
-                *reinterpret_cast<uint4*>(buf + K::IN_BYTES + (d >> 3) * K::DSTRIDE + (d & 7) * 16) = v;
-            }
+            if (info[j] >= 0) *reinterpret_cast<uint4*>(buf + (info[j] & 0xfffff)) = v;
         }
         return true;
     };
 
     auto compute = [&](const char* buf) {
-        const char* lds_in = buf;
+        const char* lds_in = buf + mt * K::IN_REGION;
         const char* lds_dy = buf + K::IN_BYTES;
         const int li = lane & 15, g16 = lane >> 4;
         const int q = li >> 2, pp4 = li & 3;
         const int csub = 16 * (g16 & 1) + 4 * pp4;  // channel offset inside the 32-row tile
-#pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
-            const int r = ks >> 1, x0 = (ks & 1) * 16;
-            const int pj = x0 + 8 * half + q;
-            bf16x8 bfrag;
-            {
-                const char* a0 = lds_dy + (r * TW + pj) * K::DSTRIDE + (32 * nt + csub) * 2;
+        const int pj = 16 * kh + 8 * half + q;
+#pragma unroll 1
+        for (int r = 0; r < TH; ++r) {
+            bf16x8 bfrag[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const char* a0 = lds_dy + n * K::DY_REGION + (r * TW + pj) * K::RSTRIDE + csub * 2;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::DSTRIDE));
+                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::RSTRIDE));
                 const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bfrag = __builtin_bit_cast(bf16x8, both);
+                bfrag[n] = __builtin_bit_cast(bf16x8, both);
             }
             if (does_bias) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)bfrag[j];
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[n] += (float)bfrag[n][j];
             }
 #pragma unroll
             for (int i = 0; i < K::NSLOT; ++i) {
                 if (i < ntaps) {
                     const int tap = tap0 + i;
                     const int dy = tap / 3, dx = tap - dy * 3;
-                    const char* a0 = lds_in + ((r + dy) * HALO_W + pj + dx) * K::PSTRIDE + (32 * mt + csub) * 2;
+                    const char* a0 = lds_in + ((r + dy) * HALO_W + pj + dx) * K::RSTRIDE + csub * 2;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(a0));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::PSTRIDE));
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::RSTRIDE));
                     const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag, acc[i], 0, 0, 0);
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, both);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[1], acc[i][1], 0, 0, 0);
                 }
             }
         }
     };
 
-    stage_load(0);
+    load_begin(0);
+    load_rest(std::integral_constant<int, 0>{});
+    if constexpr (K::CPT < MT * 32) {
+        // channels past the real ones are never staged: clear them once so that the unused
+        // accumulator rows they feed stay finite
+        for (int i = tid; i < 2 * MT * NPX * 4; i += kPPThreads) {
+            const int bufi = i / (MT * NPX * 4), rem = i - bufi * (MT * NPX * 4);
+            const int region = rem / (NPX * 4), c = rem - region * (NPX * 4);
+            if (region * 4 + (c & 3) >= K::CPT / 8)
+                *reinterpret_cast<uint4*>(smem + bufi * K::BUF_BYTES + region * K::IN_REGION + c * 16) =
+                    make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     bool live = stage_store(0, smem);
     __syncthreads();
+#ifdef ISG_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(t_begin);
     for (int k = 0; k < n_iter; ++k) {
-        stage_load(k + 1);
+        STAMP(t0);
+        load_begin(k + 1);
+        load_rest(std::integral_constant<int, 0>{});
+        STAMP(t1);
         if (live) compute(smem + (k & 1) * K::BUF_BYTES);
+        STAMP(t2);
         live = stage_store(k + 1, smem + ((k + 1) & 1) * K::BUF_BYTES);
+        STAMP(t3);
+        __syncthreads();
+        STAMP(t4);
+        STAMP_ADD(0, t0, t1);  // issue of the next tile's loads
+        STAMP_ADD(1, t1, t2);  // k-loop
+        STAMP_ADD(2, t2, t3);  // wait for the loads + LDS writes
+        STAMP_ADD(4, t3, t4);  // barrier
+    }
+#ifdef ISG_STAMPS
+    STAMP(t_end);
+    stamp_sum[6] = t_end - t_begin;
+    stamp_sum[7] = n_iter;
+    if (g_stamp_buf != nullptr && lane == 0 && (wave == 0 || wave == 7))
+        for (int k = 0; k < 8; ++k) g_stamp_buf[(blockIdx.x * 2 + (wave == 7)) * 8 + k] = stamp_sum[k];
+#endif
+
+    // ---- sum the two pixel halves (kh partners are waves 2q and 2q + 1) through LDS, one tap slot at a time ----
+    float* red = reinterpret_cast<float*>(smem) + (size_t)(wave >> 1) * (2 * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < K::NSLOT; ++i) {
+        if (kh == 1 && i < ntaps) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) red[(n * 16 + reg) * 64 + lane] = acc[i][n][reg];
+        }
+        __syncthreads();
+        if (kh == 0 && i < ntaps) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[i][n][reg] += red[(n * 16 + reg) * 64 + lane];
+        }
         __syncthreads();
     }
+    if (wave == 1) red[lane] = bsum[0], red[64 + lane] = bsum[1];  // wave 1's region is wave 0's region
+    __syncthreads();
+    if (wave == 0) bsum[0] += red[lane], bsum[1] += red[64 + lane];
+    if (kh != 0) return;
 
     float* slab = p.slab + (size_t)blockIdx.x * 9 * (MT * 32) * NG;
 #pragma unroll
@@ -580,18 +703,23 @@ __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p
         if (i < ntaps) {
             const int tap = tap0 + i;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * nt + (lane & 31);
-                *dst = p.slab_accumulate ? *dst + acc[i][reg] : acc[i][reg];
-            }
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * n + (lane & 31);
+                    *dst = p.slab_accumulate ? *dst + acc[i][n][reg] : acc[i][n][reg];
+                }
         }
     }
     if (does_bias) {
-        bsum += __shfl_xor(bsum, 32);
-        if (half == 0) {
-            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * nt + lane;
-            *dst = p.slab_accumulate ? *dst + bsum : bsum;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float v = bsum[n] + __shfl_xor(bsum[n], 32);
+            if (half == 0) {
+                float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * n + lane;
+                *dst = p.slab_accumulate ? *dst + v : v;
+            }
         }
     }
 }
@@ -629,6 +757,7 @@ int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream
 
 int launch_wgrad_pp(const WgradParams& p, int mt, int grid, hipStream_t stream) {
     if (p.c1 != F_) return kNotSupported;
+    if ((long long)p.B * p.H * p.W * NG >= (1LL << 31)) return kNotSupported;  // the kernel's element offsets are int
     if (p.c0 == 16 && mt == 1) return launch_wg<16, 1>(p, grid, stream);
     if (p.c0 == 32 && mt == 2) return launch_wg<32, 2>(p, grid, stream);
     return kNotSupported;

@@ -20,7 +20,7 @@ OUT = os.path.join(ROOT, "tools", "_build", "libisg_stamps.so")
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(ROOT, "imagesegmentation_amd", "csrc", "*.hip")))
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared",
                            "-DISG_STAMPS", "-o", OUT] + srcs)
 
 
@@ -52,8 +52,14 @@ def main():
         dy = torch.randn([B, P, P, F, 4], device=dev).bfloat16()
         dx = torch.zeros([B, P, P, cs], dtype=torch.bfloat16, device=dev)
         dhp = torch.empty_like(h)
+        dwx = torch.zeros_like(cell.input_to_state_kernel)
+        dwh = torch.zeros_like(cell.hidden_to_state_kernel)
+        db = torch.zeros_like(cell.bias)
+        # wgrad rows: "group" 0 = wave 0, 1 = wave 7; phases: load issue, k-loop, wait + LDS writes, -, barrier
         for label, fn in (("cell_fwd C=%d" % C, lambda: ops.cell_fwd(x, h, c, packed, gates=gates, hist_points=pts)),
-                          ("dgrad C=%d" % C, lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs))):
+                          ("dgrad C=%d" % C, lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs)),
+                          ("wgrad C=%d" % C, lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, False,
+                                                               hist_points=pts, hist=hist))):
             buf = torch.zeros([256 * 2 * 8], dtype=torch.int64, device=dev)
             lib.isg_debug_set_stamp_buffer(buf.data_ptr())
             fn()
