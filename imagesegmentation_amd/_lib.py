@@ -26,6 +26,9 @@ SIGNATURES = {
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
     "isg_sequence_metrics": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
+    "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),
+    "isg_relu_bwd_bias": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_avgpool_fwd": (_int, [_vp, _ll, _int, _int, _int, _int, _int, _vp, _vp]),
     "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,169 @@
+// Pointwise halves of the encoder's conv + bias + ReLU layers (reference
+// polyrnn/History2LargeExperiment.py:15-22: tf.layers.conv2d(..., activation=tf.nn.relu)).  The
+// convolution itself runs in the vendor library; bias add and ReLU are one in-place pass here instead
+// of two library passes, and their backward (ReLU mask + bias gradient) is one pass instead of three.
+// HBM-bound: every element is read once and written once with 16-byte accesses.
+#include <hip/hip_bf16.h>
+
+#include "isg_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;
+constexpr int kMaxPartialBlocks = 1024;
+
+template <typename T>
+struct Vec;
+template <>
+struct Vec<__bf16> {
+    static constexpr int N = 8;
+    using type = bf16x8;
+};
+template <>
+struct Vec<float> {
+    static constexpr int N = 4;
+    using type = f32x4;
+};
+
+// y[i][c] = max(y[i][c] + bias[c], 0), NHWC with C a multiple of the vector width
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bias_relu_kernel(T* __restrict__ y, const float* __restrict__ bias,
+                                                         long long nvec, int C) {
+    constexpr int N = Vec<T>::N;
+    using V = typename Vec<T>::type;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (long long)gridDim.x * kBlock) {
+        const int c0 = (int)((i * N) % C);
+        V v = reinterpret_cast<V*>(y)[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (T)fmaxf((float)v[k] + bias[c0 + k], 0.0f);
+        reinterpret_cast<V*>(y)[i] = v;
+    }
+}
+
+// dz = dy where y > 0 else 0; partial[block][c] = sum over the block's elements of dz[.][c].
+// A thread keeps the same channel group in every iteration (the grid stride is a multiple of C / N
+// vectors), so its N running sums belong to fixed channels.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void relu_bwd_bias_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                             T* __restrict__ dz, long long nvec, int C,
+                                                             float* __restrict__ partial) {
+    constexpr int N = Vec<T>::N;
+    using V = typename Vec<T>::type;
+    extern __shared__ float red[];  // [kBlock][N]
+    float sum[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) sum[k] = 0.0f;
+    const long long start = (long long)blockIdx.x * kBlock + threadIdx.x;
+    for (long long i = start; i < nvec; i += (long long)gridDim.x * kBlock) {
+        const V g = reinterpret_cast<const V*>(dy)[i];
+        const V a = reinterpret_cast<const V*>(y)[i];
+        V o;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float v = (float)a[k] > 0.0f ? (float)g[k] : 0.0f;
+            o[k] = (T)v;
+            sum[k] += v;
+        }
+        reinterpret_cast<V*>(dz)[i] = o;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[threadIdx.x * N + k] = sum[k];
+    __syncthreads();
+    // threads with the same (threadIdx.x mod groups) hold the same channels
+    const int groups = C / N;
+    if ((int)threadIdx.x < groups) {
+        float tot[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) tot[k] = 0.0f;
+        for (int t = threadIdx.x; t < kBlock; t += groups)
+#pragma unroll
+            for (int k = 0; k < N; ++k) tot[k] += red[t * N + k];
+        const int g0 = (int)((start % groups) * N);  // channel of this thread's first value
+#pragma unroll
+        for (int k = 0; k < N; ++k) partial[(size_t)blockIdx.x * C + g0 + k] = tot[k];
+    }
+}
+
+// one workgroup per channel: 256 threads share the per-block partial sums, then a tree in LDS
+__global__ __launch_bounds__(kBlock) void bias_partial_reduce_kernel(const float* __restrict__ partial, int nblocks,
+                                                                   int C, float* __restrict__ dbias) {
+    __shared__ float red[kBlock];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partial[(size_t)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbias[c] = red[0];
+}
+
+int check(const char* what, long long n, int C, int dtype) {
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "%s: dtype %d", what, dtype);
+    const int N = dtype == ISG_F32 ? 4 : 8;
+    ISG_REQUIRE(n >= 0 && C >= N && C % N == 0 && kBlock % (C / N) == 0, ISG_EINVAL,
+                "%s: channels must be a multiple of %d that divides %d vectors (n=%lld, C=%d)", what, N, kBlock, n, C);
+    return ISG_OK;
+}
+
+int grid_for(long long nvec) {
+    const long long want = (nvec + kBlock - 1) / kBlock;
+    return (int)(want < kMaxPartialBlocks ? (want < 1 ? 1 : want) : kMaxPartialBlocks);
+}
+
+}  // namespace
+
+extern "C" int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, void* stream) {
+    int rc = check("isg_bias_relu", n, C, dtype);
+    if (rc != ISG_OK) return rc;
+    if (n == 0) return ISG_OK;
+    ISG_REQUIRE(y && bias, ISG_EINVAL, "isg_bias_relu: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32) {
+        const long long nvec = n * C / 4;
+        hipLaunchKernelGGL(bias_relu_kernel<float>, dim3(grid_for(nvec) * 8), dim3(kBlock), 0, s, static_cast<float*>(y),
+                           bias, nvec, C);
+    } else {
+        const long long nvec = n * C / 8;
+        hipLaunchKernelGGL(bias_relu_kernel<__bf16>, dim3(grid_for(nvec) * 8), dim3(kBlock), 0, s,
+                           static_cast<__bf16*>(y), bias, nvec, C);
+    }
+    return isg::check_launch("bias_relu_kernel");
+}
+
+extern "C" long long isg_relu_bwd_bias_workspace_bytes(int C) {
+    return (long long)kMaxPartialBlocks * C * (long long)sizeof(float);
+}
+
+extern "C" int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
+                                 void* workspace, void* stream) {
+    int rc = check("isg_relu_bwd_bias", n, C, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(dbias && workspace, ISG_EINVAL, "isg_relu_bwd_bias: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) return hipMemsetAsync(dbias, 0, sizeof(float) * C, s) == hipSuccess ? ISG_OK : ISG_ELAUNCH;
+    ISG_REQUIRE(dy && y && dz, ISG_EINVAL, "isg_relu_bwd_bias: null pointer");
+    float* partial = static_cast<float*>(workspace);
+    int grid;
+    if (dtype == ISG_F32) {
+        const long long nvec = n * C / 4;
+        grid = grid_for(nvec);
+        hipLaunchKernelGGL(relu_bwd_bias_kernel<float>, dim3(grid), dim3(kBlock), kBlock * 4 * sizeof(float), s,
+                           static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<float*>(dz), nvec, C,
+                           partial);
+    } else {
+        const long long nvec = n * C / 8;
+        grid = grid_for(nvec);
+        hipLaunchKernelGGL(relu_bwd_bias_kernel<__bf16>, dim3(grid), dim3(kBlock), kBlock * 8 * sizeof(float), s,
+                           static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y), static_cast<__bf16*>(dz), nvec,
+                           C, partial);
+    }
+    if ((rc = isg::check_launch("relu_bwd_bias_kernel")) != ISG_OK) return rc;
+    hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(C), dim3(kBlock), 0, s, partial, grid, C, dbias);
+    return isg::check_launch("bias_partial_reduce_kernel");
+}

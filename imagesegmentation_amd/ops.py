@@ -187,3 +187,35 @@ def avgpool(x, k):
                                     _lib.current_stream())
     _lib.check(rc, "isg_avgpool_fwd")
     return out
+
+
+def bias_relu_(y, bias):
+    """In place y = max(y + bias, 0) on a contiguous NHWC tensor; bias float32 [C]."""
+    _need_cuda(y, "y")
+    assert y.is_contiguous() and bias.dtype == torch.float32 and bias.is_contiguous()
+    C = y.shape[-1]
+    rc = _lib.lib().isg_bias_relu(_lib.ptr(y), _lib.ptr(bias), y.numel() // C, C, dtype_code(y.dtype),
+                                  _lib.current_stream())
+    _lib.check(rc, "isg_bias_relu")
+    return y
+
+
+_bias_ws = {}
+
+
+def relu_bwd_bias(dy, y):
+    """(dz, dbias): dz = dy masked by y > 0 (written over dy when dy is contiguous and owns its memory),
+    dbias float32 [C] = sum of dz over pixels."""
+    C = y.shape[-1]
+    assert dy.is_contiguous() and y.is_contiguous()
+    key = (C, str(y.device))
+    ws = _bias_ws.get(key)
+    if ws is None:
+        ws = torch.empty([_lib.lib().isg_relu_bwd_bias_workspace_bytes(C) // 4], dtype=torch.float32, device=y.device)
+        _bias_ws[key] = ws
+    dz = torch.empty_like(dy)
+    dbias = torch.empty([C], dtype=torch.float32, device=y.device)
+    rc = _lib.lib().isg_relu_bwd_bias(_lib.ptr(dy), _lib.ptr(y), y.numel() // C, C, dtype_code(y.dtype), _lib.ptr(dz),
+                                      _lib.ptr(dbias), _lib.ptr(ws), _lib.current_stream())
+    _lib.check(rc, "isg_relu_bwd_bias")
+    return dz, dbias

@@ -39,10 +39,34 @@ def _glorot(shape, device, gen):
     return (torch.rand(shape, device=device, generator=gen) * 2 - 1) * limit
 
 
+class _BiasRelu(torch.autograd.Function):
+    """max(z + bias, 0) in place over the convolution's own output tensor (NCHW-shaped, channels-last
+    memory = NHWC; isg_bias_relu); the backward masks the gradient and sums the bias gradient in one
+    pass (isg_relu_bwd_bias).  The tensor handed in must be the convolution's result itself, not a
+    view of it: an in-place op on a view makes autograd copy whole activations."""
+
+    @staticmethod
+    def forward(ctx, z, bias):
+        assert z.is_contiguous(memory_format=torch.channels_last)
+        ops.bias_relu_(z.permute(0, 2, 3, 1), bias.detach().float().contiguous())
+        ctx.mark_dirty(z)
+        ctx.save_for_backward(z)
+        ctx.bias_dtype = bias.dtype
+        return z
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dz, dbias = ops.relu_bwd_bias(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1))
+        return dz.permute(0, 3, 1, 2), dbias.to(ctx.bias_dtype)
+
+
 def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     """tf.layers.conv2d(padding='same', activation=relu) on an NHWC tensor with an HWIO kernel
     (reference polyrnn/History2LargeExperiment.py:15-22).  Even kernels pad (k-1)//2 before and the
-    rest after, as TensorFlow's SAME does."""
+    rest after, as TensorFlow's SAME does.  The convolution is the vendor library's; bias + ReLU are
+    one fused in-place pass when the channel count allows it."""
     kh, kw = w_hwio.shape[0], w_hwio.shape[1]
     x = x_nhwc.permute(0, 3, 1, 2)  # NCHW view of channels-last memory
     pt, pl = (kh - 1) // 2, (kw - 1) // 2
@@ -52,6 +76,13 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     else:
         pad = (pt, pl)
     w = w_hwio.to(dtype).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+    cout = w_hwio.shape[3]
+    vec = 8 if dtype == torch.bfloat16 else 4
+    if x.is_cuda and cout % vec == 0 and 256 % (cout // vec) == 0:
+        z = F.conv2d(x, w, None, padding=pad)
+        if z.is_contiguous(memory_format=torch.channels_last):
+            return _BiasRelu.apply(z, b).permute(0, 2, 3, 1)
+        return torch.relu(z + b.to(dtype).view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     y = F.relu(F.conv2d(x, w, b.to(dtype), padding=pad))
     return y.permute(0, 2, 3, 1).contiguous()
 

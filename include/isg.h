@@ -202,6 +202,19 @@ int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int3
  * isg_convlstm_pointwise_bwd (dh_above_pool). */
 int isg_avgpool_fwd(const void* x, long long N, int H, int W, int F, int k, int dtype, void* out, void* stream);
 
+/* ---- encoder pointwise halves ------------------------------------------------------------------
+ * The bias + ReLU of tf.layers.conv2d(..., activation=tf.nn.relu) (reference
+ * polyrnn/History2LargeExperiment.py:15-22) around a library convolution, NHWC, n pixels of C channels
+ * (C a multiple of 8 for bf16 / 4 for float, C / that a divisor of 256).
+ * isg_bias_relu:      y = max(y + bias, 0) in place; bias float [C].
+ * isg_relu_bwd_bias:  dz = dy where y > 0 else 0 (dz may alias dy); dbias[c] = sum of dz[., c] (float,
+ *                     overwritten, deterministic two-stage sum).  workspace: device scratch of
+ *                     isg_relu_bwd_bias_workspace_bytes(C) bytes. */
+int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, void* stream);
+long long isg_relu_bwd_bias_workspace_bytes(int C);
+int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
+                      void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,3 +230,21 @@ def test_pooled_head_matches_cpu_port_with_mean_pool():
     ref_grads += [tp["dense"]["w"].grad, tp["dense"]["b"].grad]
     for p, g in zip(model.trainable_variables, ref_grads):
         assert rel_err(p.grad, g.numpy()) < 2e-4, (tuple(p.shape), rel_err(p.grad, g.numpy()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [16, 32])
+def test_fused_bias_relu_and_its_backward(dtype, C):
+    from imagesegmentation_amd import ops
+    g = torch.Generator(device="cuda:0").manual_seed(C)
+    z = torch.randn([3, 20, 28, C], device="cuda:0", generator=g).to(dtype)
+    bias = torch.randn([C], device="cuda:0", generator=g)
+    ref = torch.relu(z.float() + bias).to(dtype)
+    y = ops.bias_relu_(z.clone(), bias)
+    assert torch.equal(y, ref)
+    dy = torch.randn([3, 20, 28, C], device="cuda:0", generator=g).to(dtype)
+    dz, dbias = ops.relu_bwd_bias(dy, y)
+    ref_dz = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(dz, ref_dz)
+    ref_db = ref_dz.double().sum(dim=(0, 1, 2))
+    assert float((dbias.double() - ref_db).abs().max()) <= 1e-5 * max(1.0, float(ref_db.abs().max()))
