@@ -21,6 +21,8 @@ SIGNATURES = {
     "isg_raster_iou": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "isg_shape_mask": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_history_frames": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _int, _vp]),
+    "isg_env_step": (_int, [_vp, _vp, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _int, _int, _vp, _vp, _vp, _int, _int,
+                            _vp]),
     "isg_softmax_xent_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_softmax_xent_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp]),
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),

@@ -319,6 +319,57 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
     return out, final, (Hs, Cs, Gs, packed)
 
 
+class RecurrentStepper:
+    """The stacked cells advanced one step at a time, without autograd, for decode loops and rollouts
+    (reference polyrnn/Model.py:231-249, polyrl/ReinforceOverfitExperiment.py:136-145 feed the state back
+    through placeholders).  The state lives in two ping-pong buffers per layer: a step is one fused
+    cell launch per layer and no copy.  Layer 0 takes ``static`` features [B,H,W,Cf] plus the step's
+    history points (int32 [B,hist,2], x < 0 = empty frame)."""
+
+    def __init__(self, multi, static, hist, initial_state=None):
+        cells = list(multi.cells) if isinstance(multi, MultiRNNCell) else [multi]
+        self.cells = cells
+        B, H, W, cf = static.shape
+        dev = static.device
+        dt = cells[0].compute_dtype
+        F = cells[0]._filters
+        (multi if isinstance(multi, MultiRNNCell) else MultiRNNCell(cells)).build(cf + hist, dev)
+        self.hist = int(hist)
+        pts = torch.full([B, 1, self.hist, 2], -1, dtype=torch.int32, device=dev)
+        self._seq = SequenceInput(static=static, hist_points=pts)
+        self.packed = [self._seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
+        self._seq.prepare(dt, self.packed[0].cs)
+        self.H = [torch.zeros([2, B, H, W, F], dtype=dt, device=dev) for _ in cells]
+        self.C = [torch.zeros([2, B, H, W, F], dtype=torch.float32, device=dev) for _ in cells]
+        self.out = torch.zeros([B, 1, H, W, F], dtype=dt, device=dev)
+        self.cur = 0
+        self._stride = H * W * F
+        if initial_state is not None:
+            for l, (c, h) in enumerate(initial_state):
+                self.C[l][0].copy_(c)
+                self.H[l][0].copy_(h)
+
+    @property
+    def state(self):
+        """((c, h), ...) views of the current state; overwritten two steps later."""
+        return tuple(LSTMStateTuple(self.C[l][self.cur], self.H[l][self.cur]) for l in range(len(self.cells)))
+
+    def step(self, hist_points=None, durations=None, t=0):
+        """Advances every layer once.  Returns the top layer's emitted output [B,1,H,W,F] (zero for
+        samples with t >= durations; a buffer reused by the next step)."""
+        cur, nxt = self.cur, 1 - self.cur
+        x = self._seq.get(0)
+        L = len(self.cells)
+        pts = hist_points.to(torch.int32).contiguous() if self.hist else None
+        for l in range(L):
+            ops.cell_fwd(x, self.H[l][cur], self.C[l][cur], self.packed[l], durations, t,
+                         out=self.out if l == L - 1 else None, out_batch_stride=self._stride, save_gates=False,
+                         h_out=self.H[l][nxt], c_out=self.C[l][nxt], hist_points=pts if l == 0 else None)
+            x = self.H[l][nxt]
+        self.cur = nxt
+        return self.out
+
+
 class _SequenceFunction(torch.autograd.Function):
     """MultiRNNCell + dynamic_rnn as ONE autograd node: T*L fused cell launches forward, and the
     hand-written reverse sweep (pointwise, weight-gradient and data-gradient kernels) backward."""

@@ -26,7 +26,65 @@ __global__ __launch_bounds__(256) void history_frames_kernel(const int* __restri
     }
 }
 
+// One environment per thread: the whole of a batched env.step except the reward.
+__global__ __launch_bounds__(256) void env_step_kernel(const int* __restrict__ actions, const int* __restrict__ truth,
+                                                       int truth_stride, int* __restrict__ predicted, int vcap,
+                                                       int* __restrict__ num_predicted, int* __restrict__ history, int hist,
+                                                       unsigned char* __restrict__ done, int n, int size, int end_token,
+                                                       int* __restrict__ rec_points, int* __restrict__ rec_actions,
+                                                       int* __restrict__ rec_lengths, int T, int t) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int ax = actions[2 * e], ay = actions[2 * e + 1];
+    const bool active = done[e] == 0;
+    int* hp = history + (size_t)e * hist * 2;
+    if (rec_points != nullptr)
+        for (int i = 0; i < 2 * hist; ++i) rec_points[((size_t)e * T + t) * hist * 2 + i] = hp[i];
+    if (rec_actions != nullptr) rec_actions[((size_t)e * T + t) * 2] = ax, rec_actions[((size_t)e * T + t) * 2 + 1] = ay;
+    if (rec_lengths != nullptr && active) rec_lengths[e] += 1;
+    if (!active) return;
+    const int fx = truth[(size_t)e * truth_stride], fy = truth[(size_t)e * truth_stride + 1];
+    bool terminal, push;
+    int vx = ax, vy = ay;
+    if (end_token) {
+        terminal = ax == size && ay == 0;  // the end token closes the polygon on the first true vertex
+        push = !terminal;
+        if (terminal) vx = fx, vy = fy;
+    } else {
+        terminal = ax == fx && ay == fy;
+        push = true;
+    }
+    const int slot = min(num_predicted[e], vcap - 1);
+    predicted[((size_t)e * vcap + slot) * 2] = vx;
+    predicted[((size_t)e * vcap + slot) * 2 + 1] = vy;
+    num_predicted[e] += 1;
+    if (push && hist > 0) {
+        // frames roll by one slot (the last wraps to the front), then the action takes the last slot
+        const int lx = hp[2 * (hist - 1)], ly = hp[2 * (hist - 1) + 1];
+        for (int i = hist - 1; i > 0; --i) hp[2 * i] = hp[2 * (i - 1)], hp[2 * i + 1] = hp[2 * (i - 1) + 1];
+        hp[0] = lx, hp[1] = ly;
+        hp[2 * (hist - 1)] = ax, hp[2 * (hist - 1) + 1] = ay;
+    }
+    if (terminal) done[e] = 1;
+}
+
 }  // namespace
+
+extern "C" int isg_env_step(const int32_t* actions, const int32_t* true_vertices, int true_stride, int32_t* predicted,
+                            int vcap, int32_t* num_predicted, int32_t* history_points, int hist, uint8_t* done, int n,
+                            int size, int end_token, int32_t* rec_points, int32_t* rec_actions, int32_t* rec_lengths,
+                            int T, int t, void* stream) {
+    ISG_REQUIRE(n >= 0 && vcap >= 1 && hist >= 0 && size >= 1 && true_stride >= 2, ISG_EINVAL, "isg_env_step: bad sizes");
+    ISG_REQUIRE((!rec_points && !rec_actions) || (T >= 1 && t >= 0 && t < T), ISG_EINVAL,
+                "isg_env_step: record slot %d outside [0, %d)", t, T);
+    if (n == 0) return ISG_OK;
+    ISG_REQUIRE(actions && true_vertices && predicted && num_predicted && done && (hist == 0 || history_points),
+                ISG_EINVAL, "isg_env_step: null pointer");
+    hipLaunchKernelGGL(env_step_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), actions,
+                       true_vertices, true_stride, predicted, vcap, num_predicted, history_points, hist, done, n, size,
+                       end_token, rec_points, rec_actions, rec_lengths, T, t);
+    return isg::check_launch("env_step_kernel");
+}
 
 extern "C" int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out,
                                   int out_channels, int out_offset, void* stream) {

@@ -71,46 +71,44 @@ class BatchedPolygonEnv:
         _lib.check(rc, "isg_history_frames")
 
     # -- stepping --------------------------------------------------------------------------------
-    def step(self, actions, compute_reward=True):
+    def step(self, actions, compute_reward=True, render=True, record=None, t=0):
         """actions: int tensor [N, 2] of (x, y).  Returns (state, reward float64 [N], done bool [N]).
 
-        With ``compute_reward=False`` the terminal IoU is not evaluated in this call (reward is 0);
-        use ``terminal_rewards()`` once all episodes have ended to get them in a single launch.
+        One ``isg_env_step`` launch updates every environment.  With ``compute_reward=False`` the
+        terminal IoU is not evaluated in this call (reward is 0); use ``terminal_rewards()`` once all
+        episodes have ended to get them in a single launch.  ``render=False`` skips the history frames
+        of the returned state tensor (a policy that takes the history as points does not need them).
+        ``record`` = (points int32 [N,T,hist,2], actions int32 [N,T,2], lengths int32 [N]) receives the
+        step's episode record at slot ``t``.
         """
         n = self.num_envs
-        actions = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(n, 2)
+        actions = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(n, 2).contiguous()
         if self.steps_taken >= self.vcap - self.hist:
             raise RuntimeError("episode longer than the vertex buffer (max_steps=%d)" % self.max_steps)
-        active = ~self.done
-        first_true = self.vertices[:, 0]
-        rows = torch.arange(n, device=self.device)
-        slot = self.num_predicted.long()
-        if self.end_token:
-            is_end = active & (actions[:, 0] == self.size) & (actions[:, 1] == 0)
-            appended = torch.where(is_end[:, None], first_true, actions)
-            push = active & ~is_end
-            terminal = is_end
-        else:
-            appended = actions
-            push = active
-            terminal = active & (actions == first_true).all(dim=1)
-        current = self.predicted_vertices[rows, slot.clamp(max=self.vcap - 1)]
-        self.predicted_vertices[rows, slot.clamp(max=self.vcap - 1)] = torch.where(active[:, None], appended, current)
-        self.num_predicted = self.num_predicted + active.to(torch.int32)
-        if self.hist > 0:
-            rolled = torch.roll(self.history_points, shifts=1, dims=1)
-            rolled[:, -1] = actions
-            self.history_points = torch.where(push[:, None, None], rolled, self.history_points).contiguous()
-            self._render_history()
-        self.done = self.done | terminal
+        before = self.done.clone() if compute_reward else None
+        rec_p, rec_a, rec_l, T = None, None, None, 1
+        if record is not None:
+            rec_p, rec_a, rec_l = record
+            T = rec_a.shape[1]
+            assert rec_p.is_contiguous() and rec_a.is_contiguous() and rec_l.is_contiguous()
+        rc = _lib.lib().isg_env_step(_lib.ptr(actions), _lib.ptr(self.vertices), self.vcap * 2,
+                                     _lib.ptr(self.predicted_vertices), self.vcap, _lib.ptr(self.num_predicted),
+                                     _lib.ptr(self.history_points), self.hist, _lib.ptr(self.done), n, self.size,
+                                     int(self.end_token), _lib.ptr(rec_p), _lib.ptr(rec_a), _lib.ptr(rec_l), int(T),
+                                     int(t), _lib.current_stream())
+        _lib.check(rc, "isg_env_step")
         self.steps_taken += 1
+        if render and self.hist > 0:
+            self._render_history()
         reward = torch.zeros([n], dtype=torch.float64, device=self.device)
-        if compute_reward and bool(terminal.any()):
-            idx = terminal.nonzero(as_tuple=True)[0]
-            inter, union = util.raster_iou(self.predicted_vertices[idx].contiguous(),
-                                           self.num_predicted[idx].contiguous(), self.vertices[idx].contiguous(),
-                                           self.num_vertices[idx].contiguous(), self.size)
-            reward[idx] = inter.double() / union.double()
+        if compute_reward:
+            terminal = self.done & ~before
+            if bool(terminal.any()):
+                idx = terminal.nonzero(as_tuple=True)[0]
+                inter, union = util.raster_iou(self.predicted_vertices[idx].contiguous(),
+                                               self.num_predicted[idx].contiguous(), self.vertices[idx].contiguous(),
+                                               self.num_vertices[idx].contiguous(), self.size)
+                reward[idx] = inter.double() / union.double()
         return self._state, reward, self.done.clone()
 
     def terminal_rewards(self):

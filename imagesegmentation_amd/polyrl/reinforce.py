@@ -20,7 +20,7 @@ import math
 import numpy as np
 import torch
 
-from ..convLSTM import LSTMStateTuple, SequenceInput, _run_sequence_forward
+from ..convLSTM import LSTMStateTuple, RecurrentStepper, SequenceInput, _run_sequence_forward
 from ..polyrnn import decode
 from ..polyrnn.Model import Model
 from .batched_env import BatchedPolygonEnv
@@ -173,15 +173,12 @@ class BatchedReinforce:
         lengths = torch.zeros([N], dtype=torch.int32, device=dev)
         with torch.no_grad():
             features = pol.encode(env.image)
-            state = pol.get_rnn_zero_state(N)
+            stepper = RecurrentStepper(pol.rnn, features, hist)
             for t in range(T):
-                active = ~env.done
-                points[:, t] = env.history_points
-                logits, state = pol.step_logits(features, env.history_points, state)
+                logits = pol.head(stepper.step(env.history_points))[:, 0]
                 a = pol.sample_actions(logits).to(torch.int32)
-                actions[:, t] = a
-                lengths += active.to(torch.int32)
-                env.step(a, compute_reward=False)
+                # the env kernel also files the step's history points, action and length
+                env.step(a, compute_reward=False, render=False, record=(points, actions, lengths), t=t)
             reward, inter, union = env.terminal_rewards()
             # an episode that never terminated earns nothing (the scalar loop ends it with reward 0)
             reward = torch.where(env.done, reward, torch.zeros_like(reward))

@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, util
-from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, SequenceInput, _run_sequence_forward, dynamic_rnn
+from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, RecurrentStepper, SequenceInput, dynamic_rnn
 from . import decode
 
 
@@ -388,16 +388,12 @@ class Model:
                 n = len(v)
                 for i in range(hist):
                     pts[b, 0, i] = v[(n - 1 - hist + i + 1) % n]
-            state = self.rnn.zero_state(B, self.device)
+            stepper = RecurrentStepper(self.rnn, features, hist)
             required = np.ones([B], dtype=np.uint32)
             durations = np.zeros([B], dtype=np.uint32)
-            cells = list(self.rnn.cells)
             for i in range(T):
-                seq = SequenceInput(static=features, hist_points=torch.as_tensor(pts, device=self.device))
-                seq.T = 1
                 dur_dev = torch.as_tensor(required.astype(np.int32), device=self.device)
-                out, final, _ = _run_sequence_forward(cells, seq, dur_dev, 1, [(s.c, s.h) for s in state], False)
-                state = tuple(LSTMStateTuple(c.clone(), h.clone()) for c, h in final)
+                out = stepper.step(torch.as_tensor(pts[:, 0], device=self.device), durations=dur_dev, t=0)
                 logits = self.head(out)
                 xy = decode.prediction_max(logits, self.head_size)[:, 0].cpu().numpy()
                 predicted_vertices[:, i, :] = xy
@@ -409,7 +405,7 @@ class Model:
                 if hist > 0:
                     pts = np.roll(pts, 1, axis=2)
                     pts[:, 0, -1] = frame
-        self.rnn_final_state = state
+        self.rnn_final_state = stepper.state
         return predicted_vertices, durations
 
     def _update_after_prediction(self, predicted_vertices, xy, true_vertices, b, i, required):

@@ -78,6 +78,23 @@ int isg_shape_mask(const int32_t* verts, const int32_t* nverts, int n, int vmax,
 int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out, int out_channels,
                        int out_offset, void* stream);
 
+/* One step of n lock-stepped polygon environments, everything but the reward (reference
+ * polyrl/polygon_env.py:25-46 and polyrl/polygon_env_end_token.py:25-47 for one environment):
+ * an environment that is not done appends the action to its predicted polygon (the end token
+ * (size, 0) appends the first TRUE vertex instead and ends the episode; without end token the episode
+ * ends when the action equals the first true vertex), rolls its history points (last frame wraps to the
+ * front, the action takes the last slot; not on the end token) and sets its done flag.  Done
+ * environments ignore the action.
+ *   actions int32 [n][2] (x, y); true_vertices int32, first vertex of env e at [e * true_stride];
+ *   predicted int32 [n][vcap][2]; num_predicted int32 [n]; history_points int32 [n][hist][2];
+ *   done uint8 [n].  Optional episode record (any may be NULL): rec_points int32 [n][T][hist][2] gets the
+ *   history points BEFORE the step at slot t, rec_actions int32 [n][T][2] the action, rec_lengths [n] is
+ *   incremented for environments that were not done. */
+int isg_env_step(const int32_t* actions, const int32_t* true_vertices, int true_stride, int32_t* predicted, int vcap,
+                 int32_t* num_predicted, int32_t* history_points, int hist, uint8_t* done, int n, int size,
+                 int end_token, int32_t* rec_points, int32_t* rec_actions, int32_t* rec_lengths, int T, int t,
+                 void* stream);
+
 /* ---- ConvLSTM cell ------------------------------------------------------------------------
  * One step of the reference cell (reference convLSTM.py:26-45):
  *     y = conv(h_prev, W_h, SAME) + conv(x, W_x, SAME) + b ;  j, i, f, o = split(y, 4)
