@@ -62,12 +62,35 @@ class _BiasRelu(torch.autograd.Function):
         return dz.permute(0, 3, 1, 2), dbias.to(ctx.bias_dtype)
 
 
+class _ConvIn(torch.autograd.Function):
+    """First encoder layer (image -> 32 channels, SAME, bias, ReLU) on the isg_conv_in kernels.  The
+    image gets no gradient (it is the network's input)."""
+
+    @staticmethod
+    def forward(ctx, x3, w_hwio, bias):
+        ks = w_hwio.shape[0]
+        x4 = ops.conv_in_pad_image(x3.contiguous())
+        y = ops.conv_in_fwd(x4, ops.conv_in_pack(w_hwio), bias.detach().float().contiguous(), ks, relu=True)
+        ctx.save_for_backward(x4, y)
+        ctx.ks, ctx.dtypes = ks, (w_hwio.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, y = ctx.saved_tensors
+        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), y)
+        dw = ops.conv_in_wgrad(x4, dz, ctx.ks)
+        return None, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
+
+
 def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     """tf.layers.conv2d(padding='same', activation=relu) on an NHWC tensor with an HWIO kernel
     (reference polyrnn/History2LargeExperiment.py:15-22).  Even kernels pad (k-1)//2 before and the
     rest after, as TensorFlow's SAME does.  The convolution is the vendor library's; bias + ReLU are
     one fused in-place pass when the channel count allows it."""
     kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    if not x_nhwc.requires_grad and ops.conv_in_supported(w_hwio, dtype, x_nhwc.device):
+        return _ConvIn.apply(x_nhwc, w_hwio, b)
     x = x_nhwc.permute(0, 3, 1, 2)  # NCHW view of channels-last memory
     pt, pl = (kh - 1) // 2, (kw - 1) // 2
     if kh % 2 == 0 or kw % 2 == 0:
