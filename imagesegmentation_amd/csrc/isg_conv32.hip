@@ -1,0 +1,432 @@
+// The encoder's 32 -> 32 channel convolutions (3 x 3 and 5 x 5 taps, SAME padding; reference
+// polyrnn/RNNConvExperiment's second and third tf.layers.conv2d, pattern of
+// polyrnn/History2LargeExperiment.py:15-22) as MFMA kernels, bf16 with float accumulation.
+//   forward / data gradient:  D[row][pixel] = sum_k A[row][k] * X[k][pixel]; the caller's weight image
+//       decides which of the two it is (data gradient = flipped taps, transposed channels);
+//       optional bias and ReLU in the epilogue.
+//   weight gradient:          D[cin][cout] = sum_pixels X[pixel + tap][cin] * dZ[pixel][cout].
+// These layers move 150 - 200 bytes per pixel against 18 - 51 kFLOP: HBM-bound, so the kernels are
+// plain persistent tiles with the weight image resident in LDS and the next tile in flight in
+// registers while the current one is multiplied.
+#include <hip/hip_bf16.h>
+
+#include "isg_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int C = 32;           // channels in and out
+constexpr int TW = 32;
+constexpr int kThreads = 512;   // 8 waves
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+int g_cus = 0;
+int num_cus() {
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_cus = prop.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;
+    }
+    return g_cus;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data gradient
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+struct CF {
+    static constexpr int TH = 16;                     // tile rows: 2 per wave
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int NS = KS * KS * 2;            // k-steps: taps x two 16-channel halves
+    static constexpr int HH = TH + KS - 1, HWP = TW + KS - 1;
+    static constexpr int NPIX = HH * HWP;
+    static constexpr int PSTRIDE = C * 2 + 16;        // pad spreads the 16-byte operand reads over the banks
+    static constexpr int IN_BYTES = NPIX * PSTRIDE;
+    static constexpr int W_BYTES = NS * 1024;
+    static constexpr int NLOAD = (NPIX * 4 + kThreads - 1) / kThreads;
+    static constexpr int LDS_BYTES = W_BYTES + IN_BYTES + C * 4;
+};
+
+struct Conv32Params {
+    const void* x;     // [B,H,W,32] bf16
+    const void* wimg;  // [NS][64][8] bf16
+    const float* bias; // [32] or null
+    void* y;           // [B,H,W,32] bf16
+    int B, H, W, tiles_x, tiles_y, relu;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
+    using K = CF<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w = smem;
+    char* lds_in = smem + K::W_BYTES;
+    float* lds_bias = reinterpret_cast<float*>(smem + K::W_BYTES + K::IN_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px_l = lane & 31, half = lane >> 5;
+    {
+        const uint4* src = static_cast<const uint4*>(p.wimg);
+        uint4* dst = reinterpret_cast<uint4*>(lds_w);
+        for (int i = tid; i < K::W_BYTES / 16; i += kThreads) dst[i] = src[i];
+        if (tid < C) lds_bias[tid] = p.bias ? p.bias[tid] : 0.0f;
+    }
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    const int n_iter = (ntiles + gridDim.x - 1) / gridDim.x;
+
+    auto tile_origin = [&](int k, int& b, int& ty0, int& tx0) -> bool {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return false;
+        b = tile / tiles_per_img;
+        const int rem = tile - b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        ty0 = tyi * K::TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+        return true;
+    };
+    uint4 st[K::NLOAD];
+    auto stage_load = [&](int k) {
+        int b, ty0, tx0;
+        if (!tile_origin(k, b, ty0, tx0)) return;
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = tid + kThreads * j;
+            const int px = idx >> 2, ch = idx & 3;
+            const int hy = px / K::HWP, hx = px - hy * K::HWP;
+            const int gy = ty0 + hy - K::PAD, gx = tx0 + hx - K::PAD;
+            const bool inside = px < K::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            st[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (inside) st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.x) +
+                                                                (((size_t)b * p.H + gy) * p.W + gx) * (C * 2) + ch * 16);
+        }
+    };
+    auto stage_store = [&](int k) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return;
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) {
+            const int idx = tid + kThreads * j;
+            const int px = idx >> 2, ch = idx & 3;
+            if (px < K::NPIX) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = st[j];
+        }
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int k = 0; k < n_iter; ++k) {
+        int b, ty0, tx0;
+        const bool valid = tile_origin(k, b, ty0, tx0);
+        stage_load(k + 1);
+        if (valid) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
+            const char* bb = lds_in + ((2 * wave) * K::HWP + px_l) * K::PSTRIDE + half * 16;
+            const char* aw = lds_w + lane * 16;
+#pragma unroll 6
+            for (int s = 0; s < K::NS; ++s) {
+                const int tap = s >> 1, q = s & 1;
+                const int ty = tap / KS, tx = tap - ty * KS;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bb + ((ty + pt) * K::HWP + tx) * K::PSTRIDE + q * 32);
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[pt], 0, 0, 0);
+                }
+            }
+            // epilogue: lane = pixel; its 16 accumulators are rows 8g + 4 half + i (g = reg >> 2, i = reg & 3).
+            // The two halves swap two row groups so that each lane stores whole 16-byte runs of 8 channels.
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = acc[pt][4 * g + i] + lds_bias[8 * g + 4 * half + i];
+                        if (p.relu) v[i] = fmaxf(v[i], 0.0f);
+                    }
+                    pk[g][0] = pack2(v[0], v[1]), pk[g][1] = pack2(v[2], v[3]);
+                }
+                unsigned recv[2][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const unsigned send = half ? pk[2 * c][w] : pk[2 * c + 1][w];
+                        recv[c][w] = __shfl_xor(send, 32);
+                    }
+                const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
+                if (gy < p.H && gx < p.W) {
+                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (C * 2);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int g = 2 * c + half;
+                        const uint4 out = half ? make_uint4(recv[c][0], recv[c][1], pk[g][0], pk[g][1])
+                                               : make_uint4(pk[g][0], pk[g][1], recv[c][0], recv[c][1]);
+                        *reinterpret_cast<uint4*>(dst + g * 16) = out;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading the tile
+        stage_store(k + 1);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------
+constexpr int kWgBlocks = 256;
+
+template <int KS>
+struct CWG {
+    static constexpr int TH = 8;
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int NT = KS * KS;                  // one 32 x 32 output tile per tap
+    static constexpr int BASE = NT / 4, EXTRA = NT % 4; // tiles per wave group: BASE (+1 for the first EXTRA groups)
+    static constexpr int TPW = BASE + (EXTRA ? 1 : 0);
+    static constexpr int HH = TH + KS - 1, HWP = TW + KS - 1;
+    static constexpr int NPIX = HH * HWP;
+    static constexpr int IN_BYTES = NPIX * 64;          // unpadded 64-byte pixel rows: conflict-free transposing reads
+    static constexpr int DZ_BYTES = TH * TW * 64;
+    static constexpr int BUF_BYTES = IN_BYTES + DZ_BYTES;
+    static constexpr int NLX = (NPIX * 4 + kThreads - 1) / kThreads;
+    static constexpr int NLZ = (TH * TW * 4) / kThreads;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static_assert(4 * 16 * 64 * 4 <= LDS_BYTES, "reduction scratch");
+};
+
+struct Conv32WgradParams {
+    const void* x;   // [B,H,W,32] bf16
+    const void* dz;  // [B,H,W,32] bf16
+    float* slab;     // [blocks][NT][32][32]
+    int B, H, W, tiles_x, tiles_y;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParams p) {
+    using K = CWG<KS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int kh = wave & 1, grp = wave >> 1;  // pixel half x tap group; the halves are summed through LDS at the end
+    const int t0 = grp * K::BASE + min(grp, K::EXTRA);
+    const int nt = K::BASE + (grp < K::EXTRA ? 1 : 0);
+
+    f32x16 acc[K::TPW];
+#pragma unroll
+    for (int i = 0; i < K::TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    const int n_iter = (ntiles + gridDim.x - 1) / gridDim.x;
+
+    uint4 stx[K::NLX], stz[K::NLZ];
+    auto stage_load = [&](int k) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return;
+        const int b = tile / tiles_per_img;
+        const int rem = tile - b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        const int ty0 = tyi * K::TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < K::NLX; ++j) {
+            const int idx = tid + kThreads * j;
+            const int px = idx >> 2, ch = idx & 3;
+            const int hy = px / K::HWP, hx = px - hy * K::HWP;
+            const int gy = ty0 + hy - K::PAD, gx = tx0 + hx - K::PAD;
+            const bool inside = px < K::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            stx[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (inside) stx[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.x) +
+                                                                 (((size_t)b * p.H + gy) * p.W + gx) * 64 + ch * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < K::NLZ; ++j) {
+            const int idx = tid + kThreads * j;
+            const int px = idx >> 2, ch = idx & 3;
+            const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
+            stz[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (gy < p.H && gx < p.W)
+                stz[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.dz) +
+                                                         (((size_t)b * p.H + gy) * p.W + gx) * 64 + ch * 16);
+        }
+    };
+    auto stage_store = [&](int k, char* buf) {
+        const int tile = k * gridDim.x + blockIdx.x;
+        if (k >= n_iter || tile >= ntiles) return;
+#pragma unroll
+        for (int j = 0; j < K::NLX; ++j) {
+            const int idx = tid + kThreads * j;
+            if (idx < K::NPIX * 4) *reinterpret_cast<uint4*>(buf + idx * 16) = stx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < K::NLZ; ++j) {
+            const int idx = tid + kThreads * j;
+            *reinterpret_cast<uint4*>(buf + K::IN_BYTES + idx * 16) = stz[j];
+        }
+    };
+    auto compute = [&](const char* buf) {
+        const char* lds_in = buf;
+        const char* lds_dz = buf + K::IN_BYTES;
+        const int li = lane & 15, g16 = lane >> 4;
+        const int q = li >> 2, pp4 = li & 3;
+        const int csub = 16 * (g16 & 1) + 4 * pp4;  // channel offset inside the 32 rows
+        const int pj = 16 * kh + 8 * half + q;
+#pragma unroll 1
+        for (int r = 0; r < K::TH; ++r) {
+            bf16x8 bfrag;
+            {
+                const char* a0 = lds_dz + (r * TW + pj) * 64 + csub * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfrag = __builtin_bit_cast(bf16x8, both);
+            }
+#pragma unroll
+            for (int i = 0; i < K::TPW; ++i) {
+                if (i < nt) {
+                    const int tap = t0 + i;
+                    const int ty = tap / KS, tx = tap - ty * KS;
+                    const char* a0 = lds_in + ((r + ty) * K::HWP + pj + tx) * 64 + csub * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    stage_load(0);
+    stage_store(0, smem);
+    __syncthreads();
+    for (int k = 0; k < n_iter; ++k) {
+        stage_load(k + 1);
+        if (k * (int)gridDim.x + (int)blockIdx.x < ntiles) compute(smem + (k & 1) * K::BUF_BYTES);
+        stage_store(k + 1, smem + ((k + 1) & 1) * K::BUF_BYTES);
+        __syncthreads();
+    }
+    float* red = reinterpret_cast<float*>(smem) + (size_t)grp * (16 * 64);
+#pragma unroll
+    for (int i = 0; i < K::TPW; ++i) {
+        if (kh == 1 && i < nt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[reg * 64 + lane] = acc[i][reg];
+        }
+        __syncthreads();
+        if (kh == 0 && i < nt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[i][reg] += red[reg * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (kh != 0) return;
+    float* slab = p.slab + (size_t)blockIdx.x * K::NT * 32 * 32;
+#pragma unroll
+    for (int i = 0; i < K::TPW; ++i) {
+        if (i < nt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                slab[((size_t)(t0 + i) * 32 + row) * 32 + (lane & 31)] = acc[i][reg];
+            }
+        }
+    }
+}
+
+// dw[tap][cin][cout] = sum over blocks of slab[block][tap][cin][cout]: the slab layout is HWIO already
+__global__ void conv32_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int n, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * n + idx];
+    dw[idx] = s;
+}
+
+template <int KS>
+int launch_conv32(Conv32Params& p, hipStream_t s) {
+    using K = CF<KS>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
+    p.tiles_x = (p.W + TW - 1) / TW, p.tiles_y = (p.H + K::TH - 1) / K::TH;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int per_cu = (160 * 1024) / K::LDS_BYTES >= 2 ? 2 : 1;
+    const int grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv32_kernel<KS>, dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    return isg::check_launch("conv32_kernel");
+}
+
+template <int KS>
+int launch_conv32_wgrad(Conv32WgradParams& p, float* dw, hipStream_t s) {
+    using K = CWG<KS>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
+    p.tiles_x = (p.W + TW - 1) / TW, p.tiles_y = (p.H + K::TH - 1) / K::TH;
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int grid = ntiles < kWgBlocks ? ntiles : kWgBlocks;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_wgrad_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv32_wgrad_kernel<KS>, dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    int rc = isg::check_launch("conv32_wgrad_kernel");
+    if (rc != ISG_OK) return rc;
+    const int n = K::NT * 32 * 32;
+    hipLaunchKernelGGL(conv32_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p.slab, grid, n, dw);
+    return isg::check_launch("conv32_wgrad_reduce_kernel");
+}
+
+}  // namespace
+
+extern "C" long long isg_conv32_packed_elems(int KS) {
+    if (KS != 3 && KS != 5) return -1;
+    return (long long)KS * KS * 2 * 64 * 8;
+}
+
+extern "C" int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
+                          void* y, void* stream) {
+    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "isg_conv32: kernel size %d has no instantiation (3, 5)", KS);
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv32: bad shape");
+    ISG_REQUIRE(x && wimg && y, ISG_EINVAL, "isg_conv32: null pointer");
+    Conv32Params p = {};
+    p.x = x, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return KS == 3 ? launch_conv32<3>(p, s) : launch_conv32<5>(p, s);
+}
+
+extern "C" long long isg_conv32_wgrad_workspace_bytes(int KS) {
+    if (KS != 3 && KS != 5) return -1;
+    return (long long)kWgBlocks * KS * KS * 32 * 32 * (long long)sizeof(float);
+}
+
+extern "C" int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
+                                void* stream) {
+    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "isg_conv32_wgrad: kernel size %d has no instantiation (3, 5)", KS);
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv32_wgrad: bad shape");
+    ISG_REQUIRE(x && dz && workspace && dw, ISG_EINVAL, "isg_conv32_wgrad: null pointer");
+    Conv32WgradParams p = {};
+    p.x = x, p.dz = dz, p.slab = static_cast<float*>(workspace), p.B = B, p.H = H, p.W = W;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return KS == 3 ? launch_conv32_wgrad<3>(p, dw, s) : launch_conv32_wgrad<5>(p, dw, s);
+}

@@ -83,6 +83,29 @@ class _ConvIn(torch.autograd.Function):
         return None, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
 
 
+class _Conv32(torch.autograd.Function):
+    """A 32 -> 32 channel encoder layer (SAME, bias, ReLU) on the isg_conv32 kernels: forward with the
+    bias and ReLU fused, backward = ReLU mask + bias gradient, data gradient, weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_hwio, bias):
+        ks = w_hwio.shape[0]
+        x = x.contiguous()
+        y = ops.conv32(x, ops.conv32_pack(w_hwio), bias.detach().float().contiguous(), ks, relu=True)
+        ctx.save_for_backward(x, y, w_hwio)
+        ctx.ks, ctx.dtypes = ks, (w_hwio.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w_hwio = ctx.saved_tensors
+        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), y)
+        dx = ops.conv32(dz, ops.conv32_pack(w_hwio, data_gradient=True), None, ctx.ks, relu=False) \
+            if ctx.needs_input_grad[0] else None
+        dw = ops.conv32_wgrad(x, dz, ctx.ks)
+        return dx, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
+
+
 def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     """tf.layers.conv2d(padding='same', activation=relu) on an NHWC tensor with an HWIO kernel
     (reference polyrnn/History2LargeExperiment.py:15-22).  Even kernels pad (k-1)//2 before and the
@@ -91,6 +114,8 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     kh, kw = w_hwio.shape[0], w_hwio.shape[1]
     if not x_nhwc.requires_grad and ops.conv_in_supported(w_hwio, dtype, x_nhwc.device):
         return _ConvIn.apply(x_nhwc, w_hwio, b)
+    if x_nhwc.dtype == dtype and ops.conv32_supported(w_hwio, dtype, x_nhwc.device):
+        return _Conv32.apply(x_nhwc, w_hwio, b)
     x = x_nhwc.permute(0, 3, 1, 2)  # NCHW view of channels-last memory
     pt, pl = (kh - 1) // 2, (kw - 1) // 2
     if kh % 2 == 0 or kw % 2 == 0:

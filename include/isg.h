@@ -252,6 +252,22 @@ long long isg_conv_in_wgrad_workspace_bytes(int KS);
 int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                       void* stream);
 
+/* ---- the encoder's 32 -> 32 channel convolutions ----------------------------------------------------
+ * KS x KS taps (KS = 3 or 5), 32 channels in and out, SAME padding, bf16 with float accumulation: the later
+ * tf.layers.conv2d layers of reference polyrnn/RNNConvExperiment.py.
+ *   isg_conv32: y [B][H][W][32] = act(sum over taps and k of A * x + bias); bias may be NULL; act = ReLU when
+ *       relu != 0.  wimg: bf16 [KS*KS*2][64][8], element [2 tap + q][32 kg + m][j] = A[tap][m][16 q + 8 kg + j].
+ *       Forward: A[tap][m][k] = w[ty][tx][k][m] (HWIO).  Data gradient: x = the output gradient,
+ *       A[tap][m][k] = w[KS-1-ty][KS-1-tx][m][k], no bias, no ReLU.
+ *   isg_conv32_wgrad: dw float [KS][KS][32][32] (HWIO, overwritten) for input x and output gradient dz
+ *       (after the ReLU mask); workspace of isg_conv32_wgrad_workspace_bytes(KS) bytes. */
+long long isg_conv32_packed_elems(int KS);
+int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
+               void* stream);
+long long isg_conv32_wgrad_workspace_bytes(int KS);
+int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif
