@@ -303,7 +303,10 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
         # None = zero state: a fill, not a copy of a zero tensor
         Cs[l][0].zero_() if c0 is None else Cs[l][0].copy_(c0)
         Hs[l][0].zero_() if h0 is None else Hs[l][0].copy_(h0)
-    out = torch.zeros([B, T, H, W, F], dtype=dt, device=dev)
+    # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
+    out = torch.empty([B, T, H, W, F], dtype=dt, device=dev)
+    if t_run < T:
+        out[:, t_run:].zero_()
     cur = 0
     for t in range(t_run):
         x = seq.get(t)
@@ -427,7 +430,8 @@ class _SequenceFunction(torch.autograd.Function):
             dx0_channels = cs0
         else:
             cf = seq.static.shape[-1]
-            d_in = torch.zeros([B, H, W, cf], dtype=dt, device=dev)
+            # the first step of the sweep (t_run - 1) overwrites, the others add: no zero fill
+            d_in = (torch.empty if t_run > 0 else torch.zeros)([B, H, W, cf], dtype=dt, device=dev)
             dx0_channels = cf
         seq._buf_t = None
         # per-workgroup weight-gradient sums stay in a private workspace over the whole sweep
@@ -451,8 +455,8 @@ class _SequenceFunction(torch.autograd.Function):
                     ops.dgrad(dy, packed[0], dh_state[0], dx=d_in[t], dx_channels=dx0_channels,
                               durations=durations_dev, t=t)
                 elif dx0_channels % 4 == 0:
-                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in, dx_channels=dx0_channels, dx_accumulate=True,
-                              durations=durations_dev, t=t)
+                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in, dx_channels=dx0_channels,
+                              dx_accumulate=t < t_run - 1, durations=durations_dev, t=t)
                 else:
                     raise NotImplementedError("static feature channels must be a multiple of 4")
         if t_run > 0:

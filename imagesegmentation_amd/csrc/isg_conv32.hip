@@ -355,13 +355,19 @@ __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParam
     }
 }
 
-// dw[tap][cin][cout] = sum over blocks of slab[block][tap][cin][cout]: the slab layout is HWIO already
-__global__ void conv32_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int n, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+// dw[tap][cin][cout] = sum over blocks of slab[block][tap][cin][cout]: the slab layout is HWIO already.
+// A workgroup owns 64 outputs; 4 groups of 64 threads sum a quarter of the slabs each.
+__global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int n,
+                                                                float* __restrict__ dw) {
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
     float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * n + idx];
-    dw[idx] = s;
+    if (idx < n)
+        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * n + idx];
+    red[sg][o] = s;
+    __syncthreads();
+    if (sg == 0 && idx < n) dw[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 template <int KS>
@@ -393,7 +399,7 @@ int launch_conv32_wgrad(Conv32WgradParams& p, float* dw, hipStream_t s) {
     int rc = isg::check_launch("conv32_wgrad_kernel");
     if (rc != ISG_OK) return rc;
     const int n = K::NT * 32 * 32;
-    hipLaunchKernelGGL(conv32_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p.slab, grid, n, dw);
+    hipLaunchKernelGGL(conv32_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, p.slab, grid, n, dw);
     return isg::check_launch("conv32_wgrad_reduce_kernel");
 }
 

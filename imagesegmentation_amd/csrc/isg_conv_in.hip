@@ -354,16 +354,24 @@ __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradPa
     }
 }
 
-// dw[ky][kx][c][o] = sum over blocks of slab[block][2 ky + kx / 8][(kx % 8) * 4 + c][o]
+// dw[ky][kx][c][o] = sum over blocks of slab[block][2 ky + kx / 8][(kx % 8) * 4 + c][o].
+// A workgroup owns 64 outputs; 4 groups of 64 threads sum a quarter of the slabs each.
 template <int KS>
-__global__ void conv_in_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= KS * KS * 3 * COUT) return;
-    const int o = idx % COUT, c = (idx / COUT) % 3, kx = (idx / (COUT * 3)) % KS, ky = idx / (COUT * 3 * KS);
-    const size_t off = ((size_t)(2 * ky + (kx >> 3)) * 32 + (kx & 7) * 4 + c) * 32 + o;
+__global__ __launch_bounds__(256) void conv_in_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks,
+                                                                 float* __restrict__ dw) {
+    __shared__ float red[4][64];
+    const int t = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + t;
+    const bool has = idx < KS * KS * 3 * COUT;
     float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * (2 * KS) * 1024 + off];
-    dw[idx] = s;
+    if (has) {
+        const int o = idx % COUT, c = (idx / COUT) % 3, kx = (idx / (COUT * 3)) % KS, ky = idx / (COUT * 3 * KS);
+        const size_t off = ((size_t)(2 * ky + (kx >> 3)) * 32 + (kx & 7) * 4 + c) * 32 + o;
+        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * (2 * KS) * 1024 + off];
+    }
+    red[sg][t] = s;
+    __syncthreads();
+    if (sg == 0 && has) dw[idx] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 int g_cus = 0;
@@ -438,6 +446,6 @@ extern "C" int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, i
     int rc = isg::check_launch("conv_in_wgrad_kernel");
     if (rc != ISG_OK) return rc;
     const int n_out = 14 * 14 * 3 * COUT;
-    hipLaunchKernelGGL(conv_in_wgrad_reduce_kernel<14>, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, grid, dw);
+    hipLaunchKernelGGL(conv_in_wgrad_reduce_kernel<14>, dim3((n_out + 63) / 64), dim3(256), 0, s, p.slab, grid, dw);
     return isg::check_launch("conv_in_wgrad_reduce_kernel");
 }

@@ -494,15 +494,18 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
 }
 
 // dw_x[tap][c][gate*F+ch] (+)= sum_blocks slab[blk][tap][c][ch*4+gate], same for dw_h and dbias.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nblk,
-                                    int MT, int C, int Cw, int Cs, int accumulate, float* __restrict__ dw_x,
-                                    float* __restrict__ dw_h, float* __restrict__ dbias) {
+// A workgroup owns 64 outputs; its 4 groups of 64 threads each sum a quarter of the slabs, LDS adds the four.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                         const float* __restrict__ bias_slab, int nblk, int MT, int C,
+                                                         int Cw, int Cs, int accumulate, float* __restrict__ dw_x,
+                                                         float* __restrict__ dw_h, float* __restrict__ dbias) {
+    __shared__ float red[4][64];
     const int n_x = 9 * C * NG, n_h = 9 * F_ * NG;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_x + n_h + NG) return;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
     const size_t per_blk = (size_t)9 * (MT * 32) * NG;
     float sum = 0.0f;
-    float* dst;
+    float* dst = nullptr;
     if (idx < n_x + n_h) {
         int tap, c, col;
         if (idx < n_x) {
@@ -521,14 +524,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, const float*
         }
         const int gate = col / F_, ch = col - gate * F_;
         const size_t off = ((size_t)tap * (MT * 32) + c) * NG + ch * 4 + gate;
-        for (int b = 0; b < nblk; ++b) sum += slab[b * per_blk + off];
-    } else {
+        for (int b = sg; b < nblk; b += 4) sum += slab[b * per_blk + off];
+    } else if (idx < n_x + n_h + NG) {
         const int col = idx - n_x - n_h;
         const int gate = col / F_, ch = col - gate * F_;
-        for (int b = 0; b < nblk; ++b) sum += bias_slab[(size_t)b * NG + ch * 4 + gate];
+        for (int b = sg; b < nblk; b += 4) sum += bias_slab[(size_t)b * NG + ch * 4 + gate];
         dst = dbias + col;
     }
-    if (dst) *dst = accumulate ? *dst + sum : sum;
+    red[sg][o] = sum;
+    __syncthreads();
+    if (sg == 0 && dst) {
+        sum = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+        *dst = accumulate ? *dst + sum : sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,22 +553,30 @@ __global__ void hist_table_kernel(const float* __restrict__ w_x, int C, int hist
 
 // dw_x[tap][C + i][:] (+)= sum over live samples of dY at the one pixel that tap reaches from the point
 template <typename T>
-__global__ void hist_wgrad_kernel(const T* __restrict__ dy, const int* __restrict__ pts, long long pts_bstride,
-                                  int hist, int B, int H, int W, int C, const int* __restrict__ durations, int t,
-                                  int accumulate, float* __restrict__ dw_x) {
+__global__ __launch_bounds__(4 * NG) void hist_wgrad_kernel(const T* __restrict__ dy, const int* __restrict__ pts,
+                                                            long long pts_bstride, int hist, int B, int H, int W, int C,
+                                                            const int* __restrict__ durations, int t, int accumulate,
+                                                            float* __restrict__ dw_x) {
+    __shared__ float red[4][NG];
     const int tap = blockIdx.x / hist, i = blockIdx.x - tap * hist;
-    const int k = threadIdx.x;  // dY channel, (channel, gate) order
+    const int k = threadIdx.x & (NG - 1);  // dY channel, (channel, gate) order
+    const int sg = threadIdx.x / NG;       // the samples are dealt to 4 groups of threads
     const int ty = tap / 3, tx = tap - ty * 3;
     float sum = 0.0f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = sg; b < B; b += 4) {
         if (durations != nullptr && t >= durations[b]) continue;
         const int px = pts[(size_t)b * pts_bstride + 2 * i], py = pts[(size_t)b * pts_bstride + 2 * i + 1];
         const int gy = py - ty + 1, gx = px - tx + 1;
         if (px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
             sum += (float)dy[(((size_t)b * H + gy) * W + gx) * NG + k];
     }
-    float* dst = dw_x + ((size_t)tap * (C + hist) + C + i) * NG + (k & 3) * F_ + (k >> 2);
-    *dst = accumulate ? *dst + sum : sum;
+    red[sg][k] = sum;
+    __syncthreads();
+    if (sg == 0) {
+        sum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        float* dst = dw_x + ((size_t)tap * (C + hist) + C + i) * NG + (k & 3) * F_ + (k >> 2);
+        *dst = accumulate ? *dst + sum : sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -833,17 +849,17 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
     if ((rc = isg::check_launch("conv_wgrad_kernel")) != ISG_OK) return rc;
     if (!deferred) {
         const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, p.slab, p.bias_slab, grid,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, s, p.slab, p.bias_slab, grid,
                            MT, C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
         if ((rc = isg::check_launch("wgrad_reduce_kernel")) != ISG_OK) return rc;
     }
     if (hist > 0) {
         ISG_REQUIRE(hist_points, ISG_EINVAL, "isg_convlstm_wgrad: history points are needed when hist > 0");
         if (dtype == ISG_F32)
-            hipLaunchKernelGGL(hist_wgrad_kernel<float>, dim3(9 * hist), dim3(NG), 0, s, static_cast<const float*>(dy),
+            hipLaunchKernelGGL(hist_wgrad_kernel<float>, dim3(9 * hist), dim3(4 * NG), 0, s, static_cast<const float*>(dy),
                                hist_points, hist_batch_stride, hist, B, H, W, C, durations, t, accumulate, dw_x);
         else
-            hipLaunchKernelGGL(hist_wgrad_kernel<__bf16>, dim3(9 * hist), dim3(NG), 0, s,
+            hipLaunchKernelGGL(hist_wgrad_kernel<__bf16>, dim3(9 * hist), dim3(4 * NG), 0, s,
                                static_cast<const __bf16*>(dy), hist_points, hist_batch_stride, hist, B, H, W, C,
                                durations, t, accumulate, dw_x);
         rc = isg::check_launch("hist_wgrad_kernel");
@@ -863,7 +879,7 @@ extern "C" int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, in
     const float* slab = static_cast<const float*>(workspace);
     const float* bias_slab = slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
     const int n_out = 9 * C * NG + 9 * F_ * NG + NG;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_out + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
                        slab, bias_slab, grid, MT, C, C + hist, Cs, accumulate, dw_x, dw_h, dbias);
     return isg::check_launch("wgrad_reduce_kernel");
 }
