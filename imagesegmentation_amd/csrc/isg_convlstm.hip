@@ -761,7 +761,10 @@ extern "C" int isg_convlstm_dgrad(const void* dy, const void* packed_dgrad, int 
     const int MT = (Cs + F_ + 31) / 32;
     p.a_sstride = 1, p.a_tstride = 9 * p.spt;  // row-tile-major image
     if (dtype == ISG_BF16) {
-        // fast path: one ping-pong launch per 32-row tile of the image (each re-stages dY from L2)
+        // fast paths: all row tiles in one ping-pong launch on 4-row pixel tiles (two row tiles), else one
+        // launch per 32-row tile of the image (each re-stages dY)
+        rc = launch_conv_pp(p, MT, 1, num_cus(), s);
+        if (rc != kNotSupported) return rc;
         bool fast = true;
         for (int tile = 0; tile < MT && fast; ++tile) {
             ConvParams q = p;

@@ -51,17 +51,21 @@ __device__ __forceinline__ int scalar_load(const int* base, long long index) {
         (const __attribute__((address_space(4))) char*)(unsigned long long)(base) + i * 4);
 }
 
-template <int C0, int C1, int MT, int MODE>
+// NPT = tile rows per wave: 2 -> the 8 x 32 tile every kernel uses; 1 -> a 4 x 32 tile, whose smaller halo
+// image leaves LDS room for a two-row-tile weight image (the 48-row data gradient of layer 0 in ONE launch)
+template <int C0, int C1, int MT, int MODE, int NPT = 2>
 struct PP {
+    static constexpr int TH_ = 4 * NPT;
+    static constexpr int NPX_ = (TH_ + 2) * HALO_W;
     static constexpr int CPT = C0 + C1;          // staged channels per pixel
     static constexpr int NCH0 = C0 / 8;          // 16-byte chunks of in0 per pixel
     static constexpr int NCH = CPT / 8;
     static constexpr int SPT = CPT / 16;         // k-steps per tap
     static constexpr int NS = 9 * SPT;
     static constexpr int PSTRIDE = CPT * 2 + 16;  // LDS bytes per staged pixel (pad spreads banks)
-    static constexpr int IN_BYTES = (NPX * PSTRIDE + 15) & ~15;
+    static constexpr int IN_BYTES = (NPX_ * PSTRIDE + 15) & ~15;
     static constexpr int W_BYTES = NS * MT * 1024;
-    static constexpr int NLOAD = (NPX * NCH + 255) / 256;  // staged chunks per thread per tile
+    static constexpr int NLOAD = (NPX_ * NCH + 255) / 256;  // staged chunks per thread per tile
     static constexpr int TAB_FLOATS = NG + 9 * 2 * NG;     // bias + history taps (hist <= 2)
     static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + (MODE == 0 ? TAB_FLOATS * 4 : 0);
 };
@@ -69,9 +73,10 @@ struct PP {
 // EARLY: request the tile after next already in the finish phase (two phases of flight, ahead of the
 // phase's stores) instead of at the start of the compute phase (one phase of flight).  Measured at
 // 224 x 224: better for the 48-channel forward cell, worse for the others.
-template <int C0, int C1, int MT, int MODE, bool EARLY>
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
 __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
-    using K = PP<C0, C1, MT, MODE>;
+    using K = PP<C0, C1, MT, MODE, NPT>;
+    static_assert(NPT == 2 || MODE == 1, "the 4-row tile is for the data gradient");
     using T = __bf16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             r.b = tile / tiles_per_img;
             const int rem = tile - r.b * tiles_per_img;
             const int tyi = rem / p.tiles_x;
-            r.ty0 = tyi * TH, r.tx0 = (rem - tyi * p.tiles_x) * TW;
+            r.ty0 = tyi * K::TH_, r.tx0 = (rem - tyi * p.tiles_x) * TW;
         }
         return r;
     };
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                                      // 2 * NLOAD loop-invariant registers alive across the k-loop
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const int idx = min(g + 256 * j, NPX * K::NCH - 1);
+            const int idx = min(g + 256 * j, K::NPX_ * K::NCH - 1);
             const int px = idx / K::NCH, ch = idx - px * K::NCH;
             const int hy = px / HALO_W, hx = px - hy * HALO_W;
             const int gy = r.ty0 + hy - 1, gx = r.tx0 + hx - 1;
@@ -162,28 +167,32 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             const int px = idx / K::NCH, ch = idx - px * K::NCH;
             const bool in = (st_inside >> j) & 1u;
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
-            if (idx < NPX * K::NCH) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = v;
+            if (idx < K::NPX_ * K::NCH) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = v;
         }
     };
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][NPT];
     auto mainloop = [&]() {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
-        const char* bb = lds_in + ((2 * wave) * HALO_W + px_l) * K::PSTRIDE + half * 16;
+        const char* bb = lds_in + ((NPT * wave) * HALO_W + px_l) * K::PSTRIDE + half * 16;
         const char* aw = lds_w + lane * 16;
-        bf16x8 a[2][MT], bf[2][2];
+        bf16x8 a[2][MT], bf[2][NPT];
         auto fetch = [&](int s, int slot) {
             const int tap = s / K::SPT, q = s - tap * K::SPT;
             const int off = ((tap / 3) * HALO_W + (tap % 3)) * K::PSTRIDE + q * 32;
+            // the forward image interleaves the row tiles per k-step; the data-gradient image keeps each row
+            // tile's k-steps together (a launch may also take a single tile of it)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(aw + (s * MT + t) * 1024);
-            bf[slot][0] = *reinterpret_cast<const bf16x8*>(bb + off);
-            bf[slot][1] = *reinterpret_cast<const bf16x8*>(bb + HALO_W * K::PSTRIDE + off);
+            for (int t = 0; t < MT; ++t)
+                a[slot][t] = *reinterpret_cast<const bf16x8*>(aw + (MODE == 1 ? t * K::NS + s : s * MT + t) * 1024);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+                bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + pt * HALO_W * K::PSTRIDE + off);
         };
         fetch(0, 0);
 #pragma unroll
@@ -191,10 +200,10 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             const int cur = s & 1;
             if (s + 1 < K::NS) fetch(s + 1, cur ^ 1);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t], bf[cur][0], acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t], bf[cur][1], acc[t][1], 0, 0, 0);
-            }
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt)
+                    acc[t][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t], bf[cur][pt], acc[t][pt], 0, 0, 0);
             // keep the prefetch distance at one k-step: without this fence the scheduler hoists many
             // steps of LDS reads ahead and the register file overflows into scratch
             __builtin_amdgcn_sched_barrier(0);
@@ -204,13 +213,13 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     // Operands the epilogue needs from global memory (previous cell state, or the running dx sum when
     // accumulating) are requested at the START of the compute phase and consumed one phase later, so
     // no load latency is exposed between the MFMAs and the stores.
-    constexpr int NPRE = MODE == 0 ? 4 : 2 * MT * 4;
+    constexpr int NPRE = MODE == 0 ? 4 : NPT * MT * 4;
     uint4 pre[NPRE];
     auto prefetch_epilogue = [&](const TileRef& r) {
         if (!(r.valid && r.live)) return;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int gy = min(r.ty0 + 2 * wave + pt, p.H - 1), gx = min(r.tx0 + px_l, p.W - 1);
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int gy = min(r.ty0 + NPT * wave + pt, p.H - 1), gx = min(r.tx0 + px_l, p.W - 1);
             const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
             if constexpr (MODE == 0) {
                 const uint4* src = reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half);
@@ -237,14 +246,14 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         if (!r.valid) return;
         if (!r.live) {
             if constexpr (MODE == 0) lstm_copy_through_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256);
-            else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256);
+            else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             return;
         }
         const int hpx[2] = {p.hist > 0 ? r.hp[0] : -1, p.hist > 1 ? r.hp[2] : -1};
         const int hpy[2] = {r.hp[1], r.hp[3]};
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int gy = r.ty0 + 2 * wave + pt, gx = r.tx0 + px_l;
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int gy = r.ty0 + NPT * wave + pt, gx = r.tx0 + px_l;
             if (gy >= p.H || gx >= p.W) continue;
             if constexpr (MODE == 0) {
                 // one channel at a time: 4 accumulator registers + bias (+ history taps) -> gates ->
@@ -389,18 +398,21 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #endif
 }
 
-template <int C0, int C1, int MT, int MODE, bool EARLY>
-int launch_pp(const ConvParams& p, int num_cus, hipStream_t stream) {
-    using K = PP<C0, C1, MT, MODE>;
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
+int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
+    using K = PP<C0, C1, MT, MODE, NPT>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
-    if (MODE == 0 && p.hist > 2) return kNotSupported;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY>),
+    if (MODE == 0 && p0.hist > 2) return kNotSupported;
+    ConvParams p = p0;
+    p.tiles_y = (p.H + K::TH_ - 1) / K::TH_;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int pairs = (ntiles + 1) / 2;
     const int grid = pairs < num_cus ? pairs : num_cus;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream,
+                       p);
     return isg::check_launch("conv3x3_pp_kernel");
 }
 
@@ -752,6 +764,7 @@ int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream
         return kNotSupported;
     }
     if (p.c0 == NG && p.c1 == 0 && mt == 1) return launch_pp<NG, 0, 1, 1, false>(p, num_cus, stream);
+    if (p.c0 == NG && p.c1 == 0 && mt == 2) return launch_pp<NG, 0, 2, 1, false, 1>(p, num_cus, stream);
     return kNotSupported;
 }
 

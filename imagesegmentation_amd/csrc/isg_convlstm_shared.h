@@ -263,10 +263,11 @@ __device__ __forceinline__ void dgrad_store4(const ConvParams& p, size_t pixel, 
 
 // A masked sample's dY is zero: dh_prev keeps the carried gradient; dx must still be defined.
 template <typename T>
-__device__ __forceinline__ void dgrad_zero_dx_tile(const ConvParams& p, int b, int ty0, int tx0, int tid, int nthreads) {
+__device__ __forceinline__ void dgrad_zero_dx_tile(const ConvParams& p, int b, int ty0, int tx0, int tid, int nthreads,
+                                                   int tile_rows = TH) {
     if (!p.dx || p.dx_accumulate) return;
     const int nq = p.dx_channels / 4;
-    for (int i = tid; i < TH * TW * nq; i += nthreads) {
+    for (int i = tid; i < tile_rows * TW * nq; i += nthreads) {
         const int q4 = i % nq, pix = i / nq;
         const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
         if (gy < p.H && gx < p.W) {

@@ -7,9 +7,8 @@
 Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of a wide coalesced
 read at 64 bytes, so the read side is doubled (all kernels here read 8 or 16 bytes per lane,
 coalesced); WRITE_SIZE is exact for wide streaming stores.  `--kernels-only` launches every label
-exactly 3 times in a fixed order, which is how dispatches are matched to labels: kernels whose
-name is unique to a label are matched by name, the data-gradient kernel (same instantiation for
-both layers, two launches per call on layer 0) by order.
+exactly 3 times in a fixed order, which is how dispatches are matched to labels: by kernel name
+(every label has its own instantiation), the two pointwise and rasteriser variants by order.
 """
 import csv
 import glob
@@ -52,9 +51,8 @@ def per_label(rows):
     pw = pick("lstm_pointwise_bwd_kernel")
     put("pointwise_bwd[layer0 C=33]", pw[:CALLS])
     put("pointwise_bwd[layer1 C=16]", pw[CALLS:])
-    dg = pick("conv3x3_pp_kernel<64, 0, 1, 1")
-    put("dgrad[layer0 C=33]", dg[:2 * CALLS], per_call=2)
-    put("dgrad[layer1 C=16]", dg[2 * CALLS:])
+    put("dgrad[layer0 C=33]", pick("conv3x3_pp_kernel<64, 0, 2, 1"))  # both row tiles in one launch (4-row pixel tiles)
+    put("dgrad[layer1 C=16]", pick("conv3x3_pp_kernel<64, 0, 1, 1"))
     put("wgrad[layer0 C=33]", pick("conv_wgrad_pp_kernel<32, 2"))
     put("wgrad[layer1 C=16]", pick("conv_wgrad_pp_kernel<16, 1"))
     ra = pick("raster_iou_kernel")
