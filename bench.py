@@ -192,7 +192,7 @@ def load_pmc_traffic():
         return {}
 
 
-def cpu_baseline_convlstm(model, batch, size, T, hist, head_size, budget_s=20.0):
+def cpu_baseline_convlstm(model, batch, size, T, hist, head_size, budget_s=12.0):
     """The same graph as stock torch CPU ops (oracle/torch_port.py) on the host cores, fp32, on a bounded
     sample of the workload (2 sequences per pass)."""
     from oracle import torch_port
@@ -224,7 +224,7 @@ def cpu_baseline_convlstm(model, batch, size, T, hist, head_size, budget_s=20.0)
         loss.backward()
         done += n
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 16:
+        if el > budget_s or done >= 512:  # bounded sample: about budget_s seconds of CPU work
             break
     return {"value": done / el, "unit": "sequences/s", "cores": threads, "kind": "port",
             "sample": "%d sequences (batch %d per pass) of the same 224x224 RNNConv workload, fwd+bwd, fp32 torch CPU "
