@@ -261,7 +261,7 @@ def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
            "counts_only_rollouts_per_s": n / ms_counts * 1e3,
            "roofline": {"bound": "hbm", "achieved": n * bytes_per / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": n * bytes_per / ms / 1e6 / HBM_PEAK_GBS,
-                        "traffic": load_pmc_traffic().get("raster_iou[masks]"),
+                        "traffic": load_pmc_traffic().get("raster_iou[masks]") if (n == 16384 and size == 224) else None,
                         "algorithmic_bytes": n * bytes_per, "kernel": "raster_iou_kernel (masks materialised)"}}
     if do_cpu:
         import oracle
@@ -292,19 +292,29 @@ def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
 
 def main():
     args = parse()
+    if os.environ.get("ISG_BENCH_WATCHDOG"):  # dump every thread's stack and exit if the run takes this long
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ISG_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+    # rehearsal on a box with fewer GPUs than ranks: ISG_DIST_BACKEND=gloo lets several ranks share a device
+    backend = os.environ.get("ISG_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if not args.no_miopen_find:
         torch.backends.cudnn.benchmark = True
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from imagesegmentation_amd.polyrnn import experiments
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -372,7 +382,9 @@ def main():
     kernels, roofline, cpu = None, None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = time_kernels(model, batch, args.dtype)
-        traffic = load_pmc_traffic()
+        # the committed counter passes were taken at the default workload only
+        default_shape = args.batch == 64 and args.size == 224 and args.dtype == "bf16"
+        traffic = load_pmc_traffic() if default_shape else {}
         for k in kernels:
             k["traffic"] = traffic.get(k["kernel"])
         dom = max(kernels, key=lambda k: k["ms"])  # every kernel class runs T times per layer and step
