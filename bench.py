@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="keep MIOpen's immediate-mode pick for the encoder convs instead of letting it time its solvers "
                          "during warm-up")
+    ap.add_argument("--a3c-envs", type=int, default=256, help="actor-critic environments per GPU (0 = skip)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -179,6 +180,33 @@ def bench_reinforce(n_envs, steps, device, rank, dtype):
     return {"envs": n_envs, "size": 28, "max_steps": 10, "rollouts_per_s_rollout_only": n_envs / t_roll,
             "rollouts_per_s_with_update": n_envs / t_step, "ms_per_step": t_step * 1e3,
             "mean_reward": float(ep["reward"].mean()), "mean_length": float(ep["lengths"].float().mean())}
+
+
+def bench_a3c(n_envs, steps, device, rank, dtype):
+    """Synchronous actor-critic updates (the a3c specification: 4 x conv32 -> ConvLSTM(32) -> policy / value heads
+    at 32 x 32, rollouts of at most 10 steps) over n_envs lock-stepped environments: env-steps per second."""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl import a3c
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    ds = data.PolygonDataset.synthetic(64, image_size=32, prediction_size=32, max_timesteps=10, history_length=2,
+                                       seed=30 + rank)
+    rs = np.random.RandomState(40 + rank)
+    idx = rs.randint(0, len(ds), [n_envs])
+    images = ds._images[idx]
+    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
+    env = BatchedPolygonEnv(ds, n_envs, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=device)
+    trainer = a3c.A3C(env, compute_dtype=dtype, seed=0)
+    trainer.process(images, polygons)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    env_steps = 0
+    for _ in range(steps):
+        batch = trainer.process(images, polygons)
+        env_steps += int(batch["lengths"].sum())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"envs": n_envs, "size": 32, "filters": 32, "env_steps_per_s": env_steps / el, "ms_per_update": el / steps * 1e3,
+            "loss": trainer.last["loss"]}
 
 
 def load_pmc_traffic():
@@ -379,6 +407,15 @@ def main():
             rl["rollouts_per_s_with_update"] = rl["envs"] / rl["ms_per_step"] * 1e3
             rl.pop("rollouts_per_s_rollout_only")
 
+    ac = None
+    if args.a3c_envs > 0:
+        ac = bench_a3c(args.a3c_envs, 2, device, rank, dtype)
+        if world > 1:
+            r = torch.tensor([ac["env_steps_per_s"]], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.SUM)
+            ac["env_steps_per_s"] = float(r.item())
+            ac["envs"] = args.a3c_envs * world
+
     kernels, roofline, cpu = None, None, None
     if rank == 0 and not args.no_kernel_timing:
         kernels = time_kernels(model, batch, args.dtype)
@@ -412,7 +449,7 @@ def main():
             (MFMA_PEAK_TFLOPS[args.dtype] * world),
             "loss": float(loss),
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
-            "iou": raster, "reinforce": rl,
+            "iou": raster, "reinforce": rl, "a3c": ac,
         }
         print(json.dumps(line))
     if world > 1:
