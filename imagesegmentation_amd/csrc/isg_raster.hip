@@ -18,11 +18,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kCoordClamp = 16383;
 
-__device__ __forceinline__ int floor_div(int n, int d) {  // d > 0
-    int q = n / d;
-    return q - ((n % d != 0) && (n < 0));
-}
-
 // bits [0, t) of the 32-pixel word that starts at pixel 32*w
 __device__ __forceinline__ uint32_t prefix_word(int t, int w) {
     int k = t - 32 * w;
@@ -35,7 +30,22 @@ struct PolyLds {
     int minr, maxr, minc, maxc;
 };
 
-// Bit words of mask row y for one polygon.
+// min(max(floor(N / D), -1), P) for D > 0, exact.  Outside (-1, P) only the clamp matters; inside, 0 <= N < P * D
+// < 2^24 is exact in float, the reciprocal estimate is off by at most one, and an integer remainder check fixes it.
+__device__ __forceinline__ int floor_div_clamped(int N, int D, int P) {
+    if (N < 0) return -1;
+    if ((long long)N >= (long long)P * D) return P;
+    int q = (int)((float)N * __builtin_amdgcn_rcpf((float)D));
+    int r = N - q * D;
+    if (r < 0) --q, r += D;
+    if (r >= D) ++q;
+    return q;
+}
+
+// Bit words of mask row y for one polygon.  Two passes: the first walks every vertex with cheap tests only
+// (vertex on the row, which edges straddle the row) and leaves a bit mask of the straddling edges; the second
+// visits just those.  Lanes are rows, so a wave pays for the largest straddle count among its rows (2 for a convex
+// polygon) instead of for every edge.
 template <int WPR>
 __device__ __forceinline__ void row_bits(const PolyLds& p, int y, int P, uint32_t (&out)[WPR]) {
     uint32_t R[WPR], L[WPR], V[WPR];
@@ -43,8 +53,9 @@ __device__ __forceinline__ void row_bits(const PolyLds& p, int y, int P, uint32_
     for (int w = 0; w < WPR; ++w) R[w] = L[w] = V[w] = 0u;
     uint32_t lodd = 0u;
     const bool live = p.nv > 0 && y >= p.minr && y <= p.maxr;
+    unsigned long long straddle = 0ull;
     if (live) {
-        int xp = p.v[2 * (p.nv - 1)], yp = p.v[2 * (p.nv - 1) + 1];
+        int yp = p.v[2 * (p.nv - 1) + 1];
         for (int i = 0; i < p.nv; ++i) {
             const int xi = p.v[2 * i], yi = p.v[2 * i + 1];
             const int y0 = yi - y, y1 = yp - y;
@@ -53,31 +64,35 @@ __device__ __forceinline__ void row_bits(const PolyLds& p, int y, int P, uint32_
                 for (int w = 0; w < WPR; ++w)
                     if ((xi >> 5) == w) V[w] |= 1u << (xi & 31);
             }
-            const bool rs = (y0 > 0) != (y1 > 0);
-            const bool ls = (y0 < 0) != (y1 < 0);
-            if (rs || ls) {
-                int D = y1 - y0;
-                int N = xi * y1 - xp * y0;
-                if (D < 0) {
-                    D = -D;
-                    N = -N;
-                }
-                if (rs) {  // pixels x with x*D < N  <=>  x < ceil(N / D)
-                    int t = floor_div(N + D - 1, D);
-                    t = min(max(t, 0), P);
-#pragma unroll
-                    for (int w = 0; w < WPR; ++w) R[w] ^= prefix_word(t, w);
-                }
-                if (ls) {  // pixels x with x*D > N  <=>  x >= floor(N / D) + 1
-                    int s = floor_div(N, D) + 1;
-                    s = min(max(s, 0), P);
-                    lodd ^= 0xFFFFFFFFu;
-#pragma unroll
-                    for (int w = 0; w < WPR; ++w) L[w] ^= prefix_word(s, w);
-                }
-            }
-            xp = xi;
+            if (((y0 > 0) != (y1 > 0)) || ((y0 < 0) != (y1 < 0))) straddle |= 1ull << i;
             yp = yi;
+        }
+    }
+    while (straddle != 0ull) {
+        const int i = __ffsll((long long)straddle) - 1;
+        straddle &= straddle - 1ull;
+        const int j = i == 0 ? p.nv - 1 : i - 1;
+        const int xi = p.v[2 * i], yi = p.v[2 * i + 1];
+        const int xp = p.v[2 * j], yp = p.v[2 * j + 1];
+        const int y0 = yi - y, y1 = yp - y;
+        const bool rs = (y0 > 0) != (y1 > 0);
+        const bool ls = (y0 < 0) != (y1 < 0);
+        int D = y1 - y0;
+        int N = xi * y1 - xp * y0;
+        if (D < 0) {
+            D = -D;
+            N = -N;
+        }
+        if (rs) {  // pixels x with x*D < N  <=>  x < ceil(N / D) = floor((N - 1) / D) + 1
+            const int t = min(max(floor_div_clamped(N - 1, D, P) + 1, 0), P);
+#pragma unroll
+            for (int w = 0; w < WPR; ++w) R[w] ^= prefix_word(t, w);
+        }
+        if (ls) {  // pixels x with x*D > N  <=>  x >= floor(N / D) + 1
+            const int s = min(max(floor_div_clamped(N, D, P) + 1, 0), P);
+            lodd ^= 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < WPR; ++w) L[w] ^= prefix_word(s, w);
         }
     }
     const int c1 = min(p.maxc, P - 1) + 1;
@@ -141,33 +156,51 @@ __global__ __launch_bounds__(kThreads) void raster_iou_kernel(
     }
     __syncthreads();
 
-    for (int row = tid; row < rows; row += kThreads) {
-        const int g = row / P;
+    for (int base = 0; base < rows; base += kThreads) {  // uniform trip count: the wave reduction below needs every lane
+        const int row = base + tid;
+        const bool active = row < rows;
+        const int g = active ? row / P : (rows - 1) / P;
         const int y = row - g * P;
-        uint32_t a[WPR], b[WPR];
-        {
-            const int* m = s_meta + g * 8;
-            PolyLds p{s_verts + g * vmax * 2, m[0], m[1], m[2], m[3], m[4]};
-            row_bits<WPR>(p, y, P, a);
-        }
-        if (npoly > 1) {
-            const int* m = s_meta + (G + g) * 8;
-            PolyLds p{s_verts + (G + g) * vmax * 2, m[0], m[1], m[2], m[3], m[4]};
-            row_bits<WPR>(p, y, P, b);
-        } else {
-#pragma unroll
-            for (int w = 0; w < WPR; ++w) b[w] = a[w];
-        }
         int ci = 0, cu = 0;
+        if (active) {
+            uint32_t a[WPR], b[WPR];
+            {
+                const int* m = s_meta + g * 8;
+                PolyLds p{s_verts + g * vmax * 2, m[0], m[1], m[2], m[3], m[4]};
+                row_bits<WPR>(p, y, P, a);
+            }
+            if (npoly > 1) {
+                const int* m = s_meta + (G + g) * 8;
+                PolyLds p{s_verts + (G + g) * vmax * 2, m[0], m[1], m[2], m[3], m[4]};
+                row_bits<WPR>(p, y, P, b);
+            } else {
 #pragma unroll
-        for (int w = 0; w < WPR; ++w) {
-            ci += __popc(a[w] & b[w]);
-            cu += __popc(a[w] | b[w]);
-            s_bits[(size_t)row * WPR + w] = a[w];
-            s_bits[(size_t)(rows + row) * WPR + w] = b[w];
+                for (int w = 0; w < WPR; ++w) b[w] = a[w];
+            }
+#pragma unroll
+            for (int w = 0; w < WPR; ++w) {
+                ci += __popc(a[w] & b[w]);
+                cu += __popc(a[w] | b[w]);
+                s_bits[(size_t)row * WPR + w] = a[w];
+                s_bits[(size_t)(rows + row) * WPR + w] = b[w];
+            }
         }
-        if (ci) atomicAdd(&s_cnt[2 * g], ci);
-        if (cu) atomicAdd(&s_cnt[2 * g + 1], cu);
+        // rows of one wave mostly belong to one rollout: one LDS atomic per wave instead of one per row
+        const int g0 = __builtin_amdgcn_readfirstlane(g);
+        if (__all(g == g0)) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ci += __shfl_xor(ci, o);
+                cu += __shfl_xor(cu, o);
+            }
+            if ((tid & 63) == 0) {
+                if (ci) atomicAdd(&s_cnt[2 * g0], ci);
+                if (cu) atomicAdd(&s_cnt[2 * g0 + 1], cu);
+            }
+        } else {
+            if (ci) atomicAdd(&s_cnt[2 * g], ci);
+            if (cu) atomicAdd(&s_cnt[2 * g + 1], cu);
+        }
     }
     __syncthreads();
     for (int g = tid; g < G && r0 + g < n; g += kThreads) {
