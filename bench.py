@@ -5,7 +5,7 @@
 
 Headline (the JSON line's metric/value): polygon sequences per second, forward + backward + optimiser,
 of the RNNConvExperiment graph (encoder 32@14,32@5,32@3 -> 2 x ConvLSTM(16) -> head) on 224 x 224
-synthetic polygons, batch 64 per GPU, teacher forced, T = 5 - BASELINE.json configs[1].  The
+synthetic polygons, batch 64 per GPU, teacher forced, T = 5.  The
 reference's dense head (P*P*16 -> P*P) has 4e10 weights at P = 224 and cannot exist; as the reference
 never runs above 28 x 28, the head here average-pools the recurrent output 8x to the 28 x 28 grid the
 reference's head was built for (Model(head_size=28)).

@@ -2,7 +2,7 @@
  *
  * The reference is pure Python (TensorFlow 1.x graph ops + scikit-image); it has no FFI of its
  * own, so each entry point below names the reference call sequence it replaces.  A reference-side
- * binding is a ctypes stub.
+ * binding is a ctypes stub: load the library after the process's HIP runtime, set argtypes, pass device pointers.
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller unless the comment says "host";
