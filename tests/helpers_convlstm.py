@@ -66,3 +66,49 @@ def params_to_torch(params, requires_grad=True):
         return {k: t64(v).requires_grad_(requires_grad) for k, v in d.items()}
     return dict(encoder=[conv(p) for p in params["encoder"]], rnn=[conv(p) for p in params["rnn"]],
                 dense=conv(params["dense"]))
+
+
+# ---- frozen oracle cases (tests/golden/convlstm_golden.npz) ---------------------------------------------
+# name -> (encoder spec, rnn layers, history length, T, end token); P = 6, B = 2 throughout.  Weights and
+# inputs are rebuilt from fixed numpy RandomState seeds (whose streams numpy keeps stable); the file
+# holds the oracle's OUTPUTS for them.
+GOLDEN_CASES = {
+    "History2Large": (((16, 5), (16, 5), (16, 3)), 2, 2, 3, False),
+    "History0": (((16, 5), (16, 5), (16, 3)), 2, 0, 3, False),
+    "RNNConv": (((32, 14), (32, 5), (32, 3)), 2, 1, 2, False),
+    "EndTokenDeep_2": (((16, 5), (16, 5)) + ((16, 3),) * 5, 5, 2, 3, True),
+}
+GOLDEN_P, GOLDEN_B = 6, 2
+
+
+def golden_case(name):
+    """(params rounded to float32, images, histories, durations, targets, encoder spec, layers, end_token)."""
+    enc, layers, hist, T, end_token = GOLDEN_CASES[name]
+    rs = np.random.RandomState(100 + sorted(GOLDEN_CASES).index(name))
+    units = GOLDEN_P * GOLDEN_P + (1 if end_token else 0)
+    params = make_params(rs, GOLDEN_P, hist, encoder=enc, layers=layers, units=units)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)  # what a float32 model can hold exactly
+    params = dict(encoder=[dict(w=f32(p["w"]), b=f32(p["b"])) for p in params["encoder"]],
+                  rnn=[dict(w_x=f32(p["w_x"]), w_h=f32(p["w_h"]), bias=f32(p["bias"])) for p in params["rnn"]],
+                  dense=dict(w=f32(params["dense"]["w"]), b=f32(params["dense"]["b"])))
+    images, histories, durations, targets = make_batch(rs, GOLDEN_B, T, GOLDEN_P, hist, end_token=end_token)
+    durations[1] = min(durations[1], 2)
+    return params, images, histories, durations, targets
+
+
+def grad_signature(g):
+    """(sum, L2 norm, dot with a fixed pseudo-random direction) of one gradient tensor: three numbers that pin
+    it as well as the tensor itself would, at a fraction of the size."""
+    g = np.asarray(g, np.float64).reshape(-1)
+    d = np.random.RandomState(g.size % 9973 + 7).standard_normal(g.size)
+    return np.array([g.sum(), np.sqrt((g * g).sum()), (g * d).sum()])
+
+
+def flat_grad_list(grads):
+    """Gradient tensors in a fixed order: encoder (w, b) ..., rnn (w_x, w_h, bias) ..., dense (w, b)."""
+    out = []
+    for g in grads["encoder"]:
+        out += [g["w"], g["b"]]
+    for g in grads["rnn"]:
+        out += [g["w_x"], g["w_h"], g["bias"]]
+    return out + [grads["dense"]["w"], grads["dense"]["b"]]

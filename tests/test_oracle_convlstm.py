@@ -104,3 +104,21 @@ def test_metrics_and_targets():
     assert oc.targets_dense(np.array([P, 0]), P) == P * P
     assert np.array_equal(oc.prediction_max(np.array([[0., 7., 7.]]), 2), [[0, 1]])  # first maximum wins
     assert np.allclose(oc.discount_rewards([0, 0, 1.0]), [0.9801, 0.99, 1.0])
+
+
+def test_oracle_reproduces_its_frozen_outputs():
+    """tests/golden/convlstm_golden.npz (made by tests/golden/make_convlstm_fixtures.py) freezes the oracle's
+    outputs on seeded instances of four experiment graphs: any drift of the restatement shows here."""
+    import os
+    from helpers_convlstm import GOLDEN_CASES, GOLDEN_P, flat_grad_list, golden_case, grad_signature
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convlstm_golden.npz"))
+    for name in sorted(GOLDEN_CASES):
+        params, images, histories, durations, targets = golden_case(name)
+        chk = np.array([images.sum(), histories.sum(), durations.sum(), targets.sum(),
+                        sum(np.abs(p["w"]).sum() for p in params["encoder"])])
+        assert np.allclose(chk, gold[name + "/input_checksum"], rtol=1e-12), "seeded inputs changed: " + name
+        loss, logits, grads = oc.model_loss_and_grads(params, images, histories, durations, targets, GOLDEN_P)
+        assert np.allclose(logits, gold[name + "/logits"], rtol=1e-9, atol=1e-12)
+        assert np.allclose([loss, *oc.metrics(logits, targets, durations, GOLDEN_P)], gold[name + "/scalars"], rtol=1e-9)
+        sig = np.stack([grad_signature(g) for g in flat_grad_list(grads)])
+        assert np.allclose(sig, gold[name + "/grad_signatures"], rtol=1e-8, atol=1e-12)
