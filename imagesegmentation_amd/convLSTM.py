@@ -312,6 +312,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
         x = seq.get(t)
         nxt = cur + 1 if save else 1 - cur
         for l in range(L):
+            ops.set_layer(l)
             ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
                          out=out[:, t] if l == L - 1 else None, out_batch_stride=T * H * W * F,
                          save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
@@ -439,6 +440,7 @@ class _SequenceFunction(torch.autograd.Function):
         for t in reversed(range(t_run)):
             x0 = seq.get(t)
             for l in reversed(range(L)):
+                ops.set_layer(l)
                 x_in = x0 if l == 0 else Hs[l - 1][t + 1]
                 if l == L - 1:
                     above, stride, k = d_out[:, t], T * (H // pool) * (W // pool) * F, pool

@@ -28,6 +28,55 @@ def padded_channels(c, dtype):
     return (c + m - 1) // m * m
 
 
+# ---- optional in-step timing -------------------------------------------------------------------------
+# ``with timeline() as tl:`` makes every wrapped op record a pair of events on the current stream around its
+# launch(es); ``tl.summary()`` gives mean milliseconds per "op[layerN]" label.  Used by the benchmark to read
+# kernel durations inside a real training step; costs nothing when off.
+_timeline = None
+_layer = 0
+
+
+def set_layer(l):
+    global _layer
+    _layer = l
+
+
+class timeline:
+    def __enter__(self):
+        global _timeline
+        self.records = []
+        _timeline = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timeline
+        _timeline = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        acc = {}
+        for label, a, b in self.records:
+            acc.setdefault(label, []).append(a.elapsed_time(b))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*args, **kwargs):
+            tl = _timeline
+            if tl is None:
+                return fn(*args, **kwargs)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(*args, **kwargs)
+            b.record()
+            tl.records.append(("%s[layer%d]" % (name, _layer), a, b))
+            return out
+        wrapper.__doc__, wrapper.__name__ = fn.__doc__, fn.__name__
+        return wrapper
+    return deco
+
+
 def _need_cuda(t, name):
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU: libisg has no CPU path" % name)
@@ -73,6 +122,7 @@ def _points_arg(hist_points, hist):
     return hist_points.data_ptr(), hist_points.stride(0)
 
 
+@_timed("cell_fwd")
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
              h_out=None, c_out=None, gates=None, hist_points=None):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
@@ -98,6 +148,7 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     return h, c, gates
 
 
+@_timed("pointwise_bwd")
 def pointwise_bwd(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, durations=None, t=0,
                   dy=None, dc_prev=None, pool=1):
     """Gate backward. Returns (dy [B,H,W,F,4], dc_prev float32 [B,H,W,F]).  ``pool`` = k > 1: dh_above is
@@ -114,6 +165,7 @@ def pointwise_bwd(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_stat
     return dy, dc_prev
 
 
+@_timed("dgrad")
 def dgrad(dy, packed, dh_prev, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0):
     """Data gradient. dh_prev [B,H,W,F] is written (left untouched for masked samples); dx optional."""
     B, H, W, F, _ = dy.shape
@@ -145,6 +197,7 @@ def wgrad_workspace(cs, f, device, cached=True):
     return ws
 
 
+@_timed("wgrad")
 def wgrad(x, h_prev, dy, c_real, dw_x, dw_h, dbias, accumulate, durations=None, t=0, hist_points=None, hist=0,
           mode=None, workspace=None):
     """Parameter gradients of one step into float32 dw_x [3,3,C+hist,4F], dw_h [3,3,F,4F], dbias [4F];
