@@ -255,3 +255,62 @@ def test_wide_cell_32_filters_forward_backward(dtype):
     close(cell.bias.grad, grads[0]["dbias"], dtype, "dbias")
     close(tc.grad, d_init[0][0], dtype, "d_init c")
     close(th.grad, d_init[0][1], dtype, "d_init h")
+
+
+def test_full_benchmark_size_properties_bf16():
+    """B=64, 224 x 224 (the benchmark's shape, far beyond what the float64 oracle finishes in seconds), bf16 fast
+    kernels, through size-independent properties: (1) zero weights give the closed form c' = c / 2,
+    h' = tanh(c') / 2; (2) per-sample results do not depend on the batch around them - samples 5..6 run alone
+    match their slice of the full run bit for bit (forward, pointwise, data gradient), which ties the full-size
+    launch to the small-size launches the oracle checks; (3) the weight gradient is additive over the batch."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell
+    dt, d = torch.bfloat16, dev()
+    B, P, C, hist = 64, 224, 33, 1
+    g = torch.Generator(device=d).manual_seed(3)
+    cell = ConvLSTMCell([P, P], 16, [3, 3], compute_dtype=dt, device=d).build(C, d)
+    packed = cell.packed(hist=hist)
+    cs = packed.cs
+    x = torch.randn([B, P, P, cs], device=d, generator=g).to(dt)
+    h = (torch.randn([B, P, P, 16], device=d, generator=g) * 0.5).to(dt)
+    c = torch.randn([B, P, P, 16], device=d, generator=g)
+    pts = torch.randint(0, P, [B, hist, 2], device=d, generator=g, dtype=torch.int32)
+    dur = torch.full([B], 3, dtype=torch.int32, device=d)
+    dur[9] = 0  # one finished sample: state passes through
+    h2, c2, gates = ops.cell_fwd(x, h, c, packed, dur, 1, hist_points=pts)
+    assert torch.equal(c2[9], c[9]) and torch.equal(h2[9], h[9])
+    sl = slice(5, 7)
+    h2s, c2s, gs = ops.cell_fwd(x[sl].contiguous(), h[sl].contiguous(), c[sl].contiguous(), packed, dur[sl].contiguous(), 1,
+                                hist_points=pts[sl].contiguous())
+    assert torch.equal(h2s, h2[sl]) and torch.equal(c2s, c2[sl]) and torch.equal(gs, gates[sl])
+    # (1) closed form with zero weights
+    zero = ConvLSTMCell([P, P], 16, [3, 3], compute_dtype=dt, device=d).build(C, d)
+    with torch.no_grad():
+        zero.input_to_state_kernel.zero_(), zero.hidden_to_state_kernel.zero_(), zero.bias.zero_()
+    hz, cz, _ = ops.cell_fwd(x, h, c, zero.packed(hist=hist), hist_points=pts)
+    assert float((cz - 0.5 * c).abs().max()) < 1e-6
+    assert float((hz.float() - 0.5 * torch.tanh(cz)).abs().max()) < 4e-3  # bf16 storage of h
+    # (2) backward pieces, slice against full
+    dh = torch.randn([B, P, P, 16], device=d, generator=g).to(dt)
+    dc = torch.randn([B, P, P, 16], device=d, generator=g)
+    dy, dcp = ops.pointwise_bwd(gates, c, c2, dh, P * P * 16, None, dc, dur, 1)
+    dys, dcps = ops.pointwise_bwd(gates[sl].contiguous(), c[sl].contiguous(), c2[sl].contiguous(), dh[sl].contiguous(),
+                                  P * P * 16, None, dc[sl].contiguous(), dur[sl].contiguous(), 1)
+    assert torch.equal(dys, dy[sl]) and torch.equal(dcps, dcp[sl])
+    assert float(dy[9].abs().max()) == 0.0
+    dx = torch.empty([B, P, P, cs], dtype=dt, device=d)
+    dhp = torch.zeros([B, P, P, 16], dtype=dt, device=d)
+    ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs, durations=dur, t=1)
+    dxs = torch.empty([2, P, P, cs], dtype=dt, device=d)
+    dhps = torch.zeros([2, P, P, 16], dtype=dt, device=d)
+    ops.dgrad(dy[sl].contiguous(), packed, dhps, dx=dxs, dx_channels=cs, durations=dur[sl].contiguous(), t=1)
+    assert torch.equal(dxs, dx[sl]) and torch.equal(dhps, dhp[sl])
+    # (3) weight gradient: full batch = sum of two halves
+    mk = lambda: (torch.zeros([3, 3, C, 64], device=d), torch.zeros([3, 3, 16, 64], device=d), torch.zeros([64], device=d))
+    full, parts = mk(), mk()
+    ops.wgrad(x, h, dy, packed.c, *full, False, dur, 1, hist_points=pts, hist=hist)
+    for lo, hi in ((0, 32), (32, 64)):
+        ops.wgrad(x[lo:hi].contiguous(), h[lo:hi].contiguous(), dy[lo:hi].contiguous(), packed.c, *parts, True,
+                  dur[lo:hi].contiguous(), 1, hist_points=pts[lo:hi].contiguous(), hist=hist)
+    for a, b, name in zip(full, parts, ("dw_x", "dw_h", "dbias")):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), name
