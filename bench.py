@@ -163,25 +163,23 @@ def bench_reinforce(n_envs, steps, device, rank, dtype):
                                        seed=10 + rank, end_token=True)
     policy = ExperimentPolicyEstimator(28, 28, max_timesteps=10, end_token=True, compute_dtype=dtype, device=device,
                                        seed=0)
-    runner = BatchedReinforce(policy, ds, n_envs)
-    # the dataset's own sampler draws without replacement; n_envs episodes reuse the 64 polygons
-    rs = np.random.RandomState(20 + rank)
-    idx = rs.randint(0, len(ds), [n_envs])
-    images = ds._images[idx]
-    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
-    runner.step(images, polygons)
+    # episodes are drawn from the device-resident copy of the dataset (64 polygons, reused with replacement
+    # beyond 64 environments, each rolled to a random start vertex): a fresh draw per rollout, no host work
+    runner = BatchedReinforce(policy, ds, n_envs, device_pool=True, pool_seed=20 + rank)
+    runner.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ep = runner.rollout(images, polygons)
+        ep = runner.rollout()
     torch.cuda.synchronize()
     t_roll = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     for _ in range(steps):
-        ep, _ = runner.step(images, polygons)
+        ep, _ = runner.step()
     torch.cuda.synchronize()
     t_step = (time.perf_counter() - t0) / steps
-    return {"envs": n_envs, "size": 28, "max_steps": 10, "rollouts_per_s_rollout_only": n_envs / t_roll,
+    return {"envs": n_envs, "size": 28, "max_steps": 10, "episode_source": "device pool",
+            "rollouts_per_s_rollout_only": n_envs / t_roll,
             "rollouts_per_s_with_update": n_envs / t_step, "ms_per_step": t_step * 1e3,
             "mean_reward": float(ep["reward"].mean()), "mean_length": float(ep["lengths"].float().mean())}
 

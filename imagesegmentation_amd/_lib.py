@@ -27,6 +27,7 @@ SIGNATURES = {
     "isg_softmax_xent_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp]),
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
+    "isg_sample_actions": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int, _vp, _vp]),
     "isg_sequence_metrics": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),

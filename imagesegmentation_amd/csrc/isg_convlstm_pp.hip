@@ -362,7 +362,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             }
             prefetch_epilogue(cur);
             STAMP(t1);
+#ifndef ISG_NO_MFMA  // diagnostic build without the k-loop: what the staging / epilogue structure alone takes
             if (cur.valid && cur.live) mainloop();
+#endif
             STAMP(t2);
             STAMP_ADD(0, t0, t1);  // issue of the prefetch loads
             STAMP_ADD(1, t1, t2);  // k-loop

@@ -120,12 +120,13 @@ template <typename T>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sample_kernel(const T* __restrict__ logits, int rows, int cols,
                                                                     unsigned long long seed,
                                                                     unsigned long long row_offset,
-                                                                    int* __restrict__ out_idx) {
+                                                                    const unsigned long long* __restrict__ offset_dev,
+                                                                    int grid_side, int* __restrict__ out_idx) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* z = logits + (size_t)row * cols;
-    const unsigned long long grow = row_offset + (unsigned long long)row;
+    const unsigned long long grow = row_offset + (offset_dev ? *offset_dev : 0ull) + (unsigned long long)row;
     const uint32_t key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9U)) ^
                          mix32((uint32_t)grow * 0x85ebca6bU + (uint32_t)(grow >> 32));
     float bv = -INFINITY;
@@ -140,7 +141,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sample_kernel(const T* __
         }
     }
     wave_argmax(bv, bi);
-    if (lane == 0) out_idx[row] = bi;
+    if (lane == 0) {
+        if (grid_side > 0) {  // as an action (x, y) = (class / P, class % P); the end token P*P is (P, 0)
+            const int x = bi / grid_side;
+            *reinterpret_cast<int2*>(out_idx + 2 * (size_t)row) = make_int2(x, bi - x * grid_side);
+        } else {
+            out_idx[row] = bi;
+        }
+    }
 }
 
 int check_rows(const char* who, int rows, int cols, int dtype) {
@@ -233,21 +241,39 @@ extern "C" int isg_argmax_rows(const void* logits, int rows, int cols, int dtype
     return isg_softmax_xent_fwd(logits, nullptr, nullptr, rows, cols, dtype, nullptr, nullptr, out_idx, stream);
 }
 
-extern "C" int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
-                               unsigned long long row_offset, int32_t* out_idx, void* stream) {
-    int rc = check_rows("isg_sample_rows", rows, cols, dtype);
+namespace {
+int launch_sample(const char* who, const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                  unsigned long long row_offset, const unsigned long long* offset_dev, int grid_side, int32_t* out,
+                  void* stream) {
+    int rc = check_rows(who, rows, cols, dtype);
     if (rc != ISG_OK) return rc;
     if (rows == 0) return ISG_OK;
-    ISG_REQUIRE(logits && out_idx, ISG_EINVAL, "isg_sample_rows: null pointer");
+    ISG_REQUIRE(logits && out, ISG_EINVAL, "%s: null pointer", who);
     const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32)
         hipLaunchKernelGGL(sample_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), rows, cols,
-                           seed, row_offset, out_idx);
+                           seed, row_offset, offset_dev, grid_side, out);
     else
         hipLaunchKernelGGL(sample_kernel<__hip_bfloat16>, grid, block, 0, s,
-                           static_cast<const __hip_bfloat16*>(logits), rows, cols, seed, row_offset, out_idx);
+                           static_cast<const __hip_bfloat16*>(logits), rows, cols, seed, row_offset, offset_dev,
+                           grid_side, out);
     return isg::check_launch("sample_kernel");
+}
+}  // namespace
+
+extern "C" int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                               unsigned long long row_offset, int32_t* out_idx, void* stream) {
+    return launch_sample("isg_sample_rows", logits, rows, cols, dtype, seed, row_offset, nullptr, 0, out_idx, stream);
+}
+
+extern "C" int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                                  unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
+                                  int32_t* out_xy, void* stream) {
+    ISG_REQUIRE(P >= 1 && cols <= P * P + P, ISG_EINVAL, "isg_sample_actions: cols=%d does not fit a %d x %d grid", cols,
+                P, P);
+    return launch_sample("isg_sample_actions", logits, rows, cols, dtype, seed, row_offset, row_offset_dev, P, out_xy,
+                         stream);
 }
 
 extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T,

@@ -17,6 +17,47 @@ import torch
 from .. import _lib, util
 
 
+class DevicePolygonPool:
+    """A dataset's images and polygons resident on the device, and ``raw_sample``'s draw (reference
+    Dataset.py:152-162: a batch of distinct indices, each polygon rolled by a random start vertex) as
+    tensor operations: resetting N environments moves nothing over PCIe and runs no Python loop.
+
+    ``sample(n)`` -> (images [n,S,S,3] in ``dtype``, vertices int32 [n,vcap,2] (rolled, zero past the
+    count), counts int32 [n], indices int64 [n]).  Indices are distinct while n <= len(dataset) (as
+    ``np.random.choice(..., replace=False)``) and drawn with replacement beyond that.  The stream is
+    torch's device generator, not numpy's: same distribution, different numbers."""
+
+    def __init__(self, dataset, device, dtype=torch.float32, vcap=util.VMAX_DEFAULT, seed=0):
+        polys = [np.asarray(v) for v in dataset._vertices]
+        self.vcap = max(int(vcap), max(len(v) for v in polys))
+        vt, nvt = util.pack_polygons(polys, vmax=self.vcap)
+        self.device = torch.device(device)
+        self.images = torch.as_tensor(np.asarray(dataset._images), device=self.device).to(dtype)
+        self.vertices = torch.from_numpy(vt).to(self.device)
+        self.counts = torch.from_numpy(nvt).to(self.device)
+        self.generator = torch.Generator(device=self.device)
+        self.generator.manual_seed(int(seed))
+        self._slot = torch.arange(self.vcap, device=self.device, dtype=torch.int64)[None, :]
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def sample(self, n):
+        m = len(self)
+        if n <= m:
+            idx = torch.randperm(m, generator=self.generator, device=self.device)[:n]
+        else:
+            idx = torch.randint(0, m, [n], generator=self.generator, device=self.device)
+        cnt = self.counts[idx].to(torch.int64)
+        start = (torch.rand([n], generator=self.generator, device=self.device, dtype=torch.float64) * cnt).long()
+        start = torch.minimum(start, cnt - 1)
+        # np.roll(p, start): rolled[j] = p[(j - start) mod count]
+        src = torch.remainder(self._slot - start[:, None], cnt[:, None])
+        rolled = torch.gather(self.vertices[idx], 1, src[:, :, None].expand(-1, -1, 2))
+        rolled = torch.where((self._slot < cnt[:, None])[:, :, None], rolled, torch.zeros_like(rolled))
+        return self.images[idx], rolled.contiguous(), cnt.to(torch.int32), idx
+
+
 class BatchedPolygonEnv:
     def __init__(self, dataset, num_envs, end_token=False, max_steps=10, device=None, state_dtype=torch.float32):
         self.dataset = dataset
@@ -29,28 +70,43 @@ class BatchedPolygonEnv:
         self.hist = int(dataset._history_length)
 
     # -- set-up ----------------------------------------------------------------------------------
-    def reset(self, images=None, polygons=None):
+    def reset(self, images=None, polygons=None, device_batch=None):
         """Samples ``num_envs`` (image, polygon) pairs (``dataset.raw_sample``) unless given, and
-        returns the state tensor [N, P, P, 3 + hist]."""
-        if images is None:
-            images, polygons = self.dataset.raw_sample(batch_size=self.num_envs)
-        n, hist, size = self.num_envs, self.hist, self.size
-        assert len(polygons) == n
-        vmax_true = max(max(len(p) for p in polygons), util.VMAX_DEFAULT)
-        self.vcap = max(vmax_true, hist + self.max_steps + 1)
-        vt, nvt = util.pack_polygons(polygons, vmax=self.vcap)
+        returns the state tensor [N, P, P, 3 + hist].  ``device_batch`` = (images, vertices int32
+        [N,V,2], counts int32 [N]) device tensors, e.g. from ``DevicePolygonPool.sample``, starts the
+        episodes without touching the host."""
+        n, hist = self.num_envs, self.hist
         dev = self.device
-        self.vertices = torch.from_numpy(vt).to(dev)
-        self.num_vertices = torch.from_numpy(nvt).to(dev)
+        if device_batch is not None:
+            img, vt, nvt = device_batch[:3]
+            assert vt.shape[0] == n and nvt.shape[0] == n and vt.dtype == torch.int32 and nvt.dtype == torch.int32
+            need = hist + self.max_steps + 1
+            if vt.shape[1] < need:
+                vt = torch.nn.functional.pad(vt, (0, 0, 0, need - vt.shape[1]))
+            self.vcap = int(vt.shape[1])
+            self.vertices, self.num_vertices = vt.contiguous(), nvt.contiguous()
+            img = img.to(self.state_dtype)
+        else:
+            if images is None:
+                images, polygons = self.dataset.raw_sample(batch_size=n)
+            assert len(polygons) == n
+            vmax_true = max(max(len(p) for p in polygons), util.VMAX_DEFAULT)
+            self.vcap = max(vmax_true, hist + self.max_steps + 1)
+            vt, nvt = util.pack_polygons(polygons, vmax=self.vcap)
+            self.vertices = torch.from_numpy(vt).to(dev)
+            self.num_vertices = torch.from_numpy(nvt).to(dev)
+            img = torch.as_tensor(np.asarray(images), device=dev).to(self.state_dtype)
+        size = self.size
         self.predicted_vertices = torch.zeros([n, self.vcap, 2], dtype=torch.int32, device=dev)
         self.predicted_vertices[:, :hist] = self.vertices[:, :hist]
         self.num_predicted = torch.full([n], hist, dtype=torch.int32, device=dev)
         self.history_points = self.vertices[:, :hist].clone().contiguous()
         self.done = torch.zeros([n], dtype=torch.bool, device=dev)
         self.steps_taken = 0
-        img = torch.as_tensor(np.asarray(images), device=dev).to(self.state_dtype)
-        self._state = torch.zeros([n, size, size, 3 + hist], dtype=self.state_dtype, device=dev)
+        self._state = torch.empty([n, size, size, 3 + hist], dtype=self.state_dtype, device=dev)
         self._state[..., :3] = img
+        if hist:
+            self._state[..., 3:] = 0
         self._render_history()
         return self._state
 
@@ -71,21 +127,15 @@ class BatchedPolygonEnv:
         _lib.check(rc, "isg_history_frames")
 
     # -- stepping --------------------------------------------------------------------------------
-    def step(self, actions, compute_reward=True, render=True, record=None, t=0):
-        """actions: int tensor [N, 2] of (x, y).  Returns (state, reward float64 [N], done bool [N]).
-
-        One ``isg_env_step`` launch updates every environment.  With ``compute_reward=False`` the
-        terminal IoU is not evaluated in this call (reward is 0); use ``terminal_rewards()`` once all
-        episodes have ended to get them in a single launch.  ``render=False`` skips the history frames
-        of the returned state tensor (a policy that takes the history as points does not need them).
-        ``record`` = (points int32 [N,T,hist,2], actions int32 [N,T,2], lengths int32 [N]) receives the
-        step's episode record at slot ``t``.
-        """
+    def advance(self, actions, record=None, t=0):
+        """One ``isg_env_step`` launch for every environment and nothing else: no reward, no rendered
+        state, no allocation.  actions: int32 device tensor [N, 2] of (x, y).  ``record`` as in ``step``."""
         n = self.num_envs
-        actions = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(n, 2).contiguous()
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        assert actions.numel() == 2 * n
         if self.steps_taken >= self.vcap - self.hist:
             raise RuntimeError("episode longer than the vertex buffer (max_steps=%d)" % self.max_steps)
-        before = self.done.clone() if compute_reward else None
         rec_p, rec_a, rec_l, T = None, None, None, 1
         if record is not None:
             rec_p, rec_a, rec_l = record
@@ -98,6 +148,21 @@ class BatchedPolygonEnv:
                                      int(t), _lib.current_stream())
         _lib.check(rc, "isg_env_step")
         self.steps_taken += 1
+
+    def step(self, actions, compute_reward=True, render=True, record=None, t=0):
+        """actions: int tensor [N, 2] of (x, y).  Returns (state, reward float64 [N], done bool [N]).
+
+        One ``isg_env_step`` launch updates every environment.  With ``compute_reward=False`` the
+        terminal IoU is not evaluated in this call (reward is 0); use ``terminal_rewards()`` once all
+        episodes have ended to get them in a single launch.  ``render=False`` skips the history frames
+        of the returned state tensor (a policy that takes the history as points does not need them).
+        ``record`` = (points int32 [N,T,hist,2], actions int32 [N,T,2], lengths int32 [N]) receives the
+        step's episode record at slot ``t``.
+        """
+        n = self.num_envs
+        actions = torch.as_tensor(actions, device=self.device).to(torch.int32).reshape(n, 2).contiguous()
+        before = self.done.clone() if compute_reward else None
+        self.advance(actions, record, t)
         if render and self.hist > 0:
             self._render_history()
         reward = torch.zeros([n], dtype=torch.float64, device=self.device)

@@ -9,7 +9,7 @@ steps weighted 0, raw (unclipped) gradients summed into a buffer and applied by 
 (reference :111-134, :147-176).  ``reinforce`` is the reference's episode loop (:279-331).
 
 ``BatchedReinforce`` runs the same algorithm for N lock-stepped rollouts per GPU: one recurrent step
-for all environments per launch, actions from isg_sample_rows, terminal IoU rewards of every rollout
+for all environments per launch, actions from isg_sample_actions, terminal IoU rewards of every rollout
 from one isg_raster_iou launch, one teacher-forced update pass over the recorded episodes, gradients
 all-reduced across ranks (RCCL) before Adam.  Episodes of one update are the batch: their
 per-episode gradients are summed exactly as the reference sums them in its gradBuffer.
@@ -23,7 +23,7 @@ import torch
 from ..convLSTM import LSTMStateTuple, RecurrentStepper, SequenceInput, _run_sequence_forward
 from ..polyrnn import decode
 from ..polyrnn.Model import Model
-from .batched_env import BatchedPolygonEnv
+from .batched_env import BatchedPolygonEnv, DevicePolygonPool
 
 
 def discount_rewards(r, gamma=0.99):
@@ -67,9 +67,10 @@ class ExperimentPolicyEstimator(Model):
 
     def sample_actions(self, logits):
         """Categorical sample per row -> (x, y) = (a // P, a % P); the end token is class P*P = (P, 0)."""
-        a = decode.sample_rows(logits, self._sample_seed, row_offset=self._sample_calls * (1 << 20))
+        a = decode.sample_actions(logits, self._sample_seed, self.action_size,
+                                  row_offset=self._sample_calls * (1 << 20))
         self._sample_calls += 1
-        return torch.stack([a // self.action_size, a % self.action_size], dim=1)
+        return a
 
     def predict(self, image, history, rnn_state):
         """Picks a single action given image [P,P,3] and history frames [P,P,hist] (reference :136-145).
@@ -115,7 +116,7 @@ class ExperimentPolicyEstimator(Model):
         self.gradBuffer += self._flat_grad
         if apply_grads:
             self.apply_accumulated()
-        return float(loss)
+        return float(loss.detach())
 
 
 def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_per_episode=None, summary_writer=None,
@@ -154,19 +155,29 @@ def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_pe
 class BatchedReinforce:
     """N lock-stepped REINFORCE rollouts per GPU against a BatchedPolygonEnv."""
 
-    def __init__(self, policy, dataset, num_envs, gamma=0.99):
+    def __init__(self, policy, dataset, num_envs, gamma=0.99, device_pool=False, pool_seed=0):
+        """``device_pool=True`` keeps the dataset on the device (``DevicePolygonPool``): rollouts that are
+        not handed explicit images / polygons then draw their episodes there instead of through
+        ``dataset.raw_sample`` on the host."""
         self.policy = policy
         self.env = BatchedPolygonEnv(dataset, num_envs, end_token=policy.end_token, max_steps=policy.max_timesteps,
                                      device=policy.device, state_dtype=torch.float32)
         self.num_envs = num_envs
         self.gamma = gamma
+        self.pool = None
+        if device_pool:
+            self.pool = DevicePolygonPool(dataset, policy.device, dtype=torch.float32,
+                                          vcap=policy.history_length + policy.max_timesteps + 1, seed=pool_seed)
 
     def rollout(self, images=None, polygons=None):
         """Runs every environment for up to max_timesteps sampled actions.  Returns a dict with the
         recorded episode (history points, actions, lengths), rewards (float64 [N]) and counts."""
         pol, env = self.policy, self.env
         N, T, hist = self.num_envs, pol.max_timesteps, pol.history_length
-        env.reset(images=images, polygons=polygons)
+        if images is None and self.pool is not None:
+            env.reset(device_batch=self.pool.sample(N))
+        else:
+            env.reset(images=images, polygons=polygons)
         dev = pol.device
         points = torch.full([N, T, hist, 2], -1, dtype=torch.int32, device=dev)
         actions = torch.zeros([N, T, 2], dtype=torch.int32, device=dev)
@@ -176,9 +187,9 @@ class BatchedReinforce:
             stepper = RecurrentStepper(pol.rnn, features, hist)
             for t in range(T):
                 logits = pol.head(stepper.step(env.history_points))[:, 0]
-                a = pol.sample_actions(logits).to(torch.int32)
+                a = pol.sample_actions(logits)
                 # the env kernel also files the step's history points, action and length
-                env.step(a, compute_reward=False, render=False, record=(points, actions, lengths), t=t)
+                env.advance(a, record=(points, actions, lengths), t=t)
             reward, inter, union = env.terminal_rewards()
             # an episode that never terminated earns nothing (the scalar loop ends it with reward 0)
             reward = torch.where(env.done, reward, torch.zeros_like(reward))

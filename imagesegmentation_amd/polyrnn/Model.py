@@ -282,7 +282,17 @@ class Model:
         if hs != P and rnn_out.shape[2] != hs:  # not pooled by the recurrence itself
             rnn_out = _AvgPool.apply(rnn_out.contiguous(), P // hs)
         flat = rnn_out.reshape(B * T, hs * hs * self.rnn_filters)
-        logits = torch.addmm(self.dense_bias.to(flat.dtype), flat, self.dense_kernel.to(flat.dtype))
+        w, b = self.dense_kernel, self.dense_bias
+        if flat.dtype != w.dtype and not torch.is_grad_enabled():
+            # decode loops call the head once per step with unchanged weights: convert them once
+            key = (flat.dtype, w._version, b._version, w.data_ptr())
+            if getattr(self, "_head_cast_key", None) != key:
+                self._head_cast = (w.detach().to(flat.dtype), b.detach().to(flat.dtype))
+                self._head_cast_key = key
+            w, b = self._head_cast
+        else:
+            w, b = w.to(flat.dtype), b.to(flat.dtype)
+        logits = torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
 
     def forward(self, images, durations, histories, initial_state=None):

@@ -94,3 +94,16 @@ def sample_rows(logits, seed, row_offset=0):
                                     _lib.ptr(out), _lib.current_stream())
     _lib.check(rc, "isg_sample_rows")
     return out.to(torch.int64).reshape(logits.shape[:-1])
+
+
+def sample_actions(logits, seed, grid_side, row_offset=0, row_offset_dev=None, out=None):
+    """One categorical sample per row, delivered as the action (x, y) = (class // P, class % P), int32
+    [rows, 2], from one launch (reference polyrl/ReinforceOverfitExperiment.py:101-105).
+    ``row_offset_dev`` (uint64/int64 device scalar) is added to ``row_offset`` on the device."""
+    z, rows, cols = _rows(logits)
+    if out is None:
+        out = torch.empty([rows, 2], dtype=torch.int32, device=z.device)
+    rc = _lib.lib().isg_sample_actions(_lib.ptr(z), rows, cols, dtype_code(z.dtype), int(seed), int(row_offset),
+                                       _lib.ptr(row_offset_dev), int(grid_side), _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_sample_actions")
+    return out

@@ -200,6 +200,14 @@ int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, const float*
 int isg_argmax_rows(const void* logits, int rows, int cols, int dtype, int32_t* out_idx, void* stream);
 int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
                     unsigned long long row_offset, int32_t* out_idx, void* stream);
+/* The same draw delivered as an action: out_xy int32 [rows][2] = (class / P, class % P), the pair the
+ * reference builds from the sampled class (polyrl/ReinforceOverfitExperiment.py:103-105); the end token
+ * (class P*P) comes out as (P, 0).  row_offset_dev (device, may be NULL) is added to row_offset when the
+ * kernel runs, so a captured HIP graph of a rollout draws fresh numbers on every replay once its owner
+ * advances that word between replays. */
+int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
+                       unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
+                       int32_t* out_xy, void* stream);
 
 /* Masked metrics of reference polyrnn/Model.py:44-54 in one launch: pred int32 [B*T] (argmax class),
  * targets int32 [B][T][2] (x, y), durations int32 [B], P = side of the class grid (class = x*P + y;
