@@ -176,9 +176,20 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt)
+            for (int pt = 0; pt < NPT; ++pt) {
+                if constexpr (MODE == 0) {
+                    // the accumulators start from the bias: the finish phase then has no table reads of its own
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
+                    for (int a4 = 0; a4 < 4; ++a4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_tab + 32 * half + 16 * t + 4 * a4);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[t][pt][4 * a4 + g] = b4[g];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
+                }
+            }
         const char* bb = lds_in + ((NPT * wave) * HALO_W + px_l) * K::PSTRIDE + half * 16;
         const char* aw = lds_w + lane * 16;
         bf16x8 a[2][MT], bf[2][NPT];
@@ -249,8 +260,18 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             return;
         }
+        // History taps touch the 3 x 3 pixels around a history point: a wave whose rows are nowhere near one
+        // (nearly every wave) skips them on a scalar test.
         const int hpx[2] = {p.hist > 0 ? r.hp[0] : -1, p.hist > 1 ? r.hp[2] : -1};
         const int hpy[2] = {r.hp[1], r.hp[3]};
+        bool near_point = false;
+        if constexpr (MODE == 0) {
+            const int wy0 = r.ty0 + NPT * wave;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                near_point |= hpx[i] >= 0 && hpy[i] >= wy0 - 1 && hpy[i] <= wy0 + NPT && hpx[i] >= r.tx0 - 1 &&
+                              hpx[i] <= r.tx0 + TW;
+        }
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int gy = r.ty0 + NPT * wave + pt, gx = r.tx0 + px_l;
@@ -264,13 +285,6 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                                      __uint_as_float(pre[2 * pt].z),     __uint_as_float(pre[2 * pt].w),
                                      __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
                                      __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
-                int tap_off[2] = {-1, -1};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ty = hpy[i] - gy + 1, tx = hpx[i] - gx + 1;
-                    if (hpx[i] >= 0 && (unsigned)ty < 3u && (unsigned)tx < 3u)
-                        tap_off[i] = NG + ((ty * 3 + tx) * p.hist + i) * NG + 32 * half;
-                }
                 T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
                 float hn[8], cn[8], gprev[4];
 #pragma unroll
@@ -278,15 +292,19 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #pragma unroll
                     for (int a4 = 0; a4 < 4; ++a4) {
                         const int cl = 4 * t + a4;
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_tab + 32 * half + 4 * cl);
-                        float z[4] = {acc[t][pt][4 * a4] + b4[0], acc[t][pt][4 * a4 + 1] + b4[1],
-                                      acc[t][pt][4 * a4 + 2] + b4[2], acc[t][pt][4 * a4 + 3] + b4[3]};
+                        float z[4] = {acc[t][pt][4 * a4], acc[t][pt][4 * a4 + 1], acc[t][pt][4 * a4 + 2],
+                                      acc[t][pt][4 * a4 + 3]};
+                        if (near_point) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (tap_off[i] >= 0) {
-                                const f32x4 tb = *reinterpret_cast<const f32x4*>(lds_tab + tap_off[i] + 4 * cl);
-                                z[0] += tb[0], z[1] += tb[1], z[2] += tb[2], z[3] += tb[3];
+                            for (int i = 0; i < 2; ++i) {
+                                const int ty = hpy[i] - gy + 1, tx = hpx[i] - gx + 1;
+                                if (hpx[i] >= 0 && (unsigned)ty < 3u && (unsigned)tx < 3u) {
+                                    const f32x4 tb = *reinterpret_cast<const f32x4*>(
+                                        lds_tab + NG + ((ty * 3 + tx) * p.hist + i) * NG + 32 * half + 4 * cl);
+                                    z[0] += tb[0], z[1] += tb[1], z[2] += tb[2], z[3] += tb[3];
+                                }
                             }
+                        }
                         const float g = act_tanh<true>(z[0]), ig = act_sigmoid<true>(z[1]);
                         const float fg = act_sigmoid<true>(z[2]), og = act_sigmoid<true>(z[3]);
                         const float c = fg * cp[cl] + ig * g;
@@ -356,11 +374,16 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     for (int h = 0; h < n_half; ++h) {
         STAMP(t0);
         if (((h + grp) & 1) == 0) {
+            // The partner wave on this SIMD is in its finish phase, a long run of vector ALU work (gate math) that
+            // would otherwise win most issue slots: the few instructions that put this phase's loads in flight go
+            // first (measured: 3 - 10 % of a launch).
+            __builtin_amdgcn_s_setprio(3);
             if constexpr (!EARLY) {
                 pending = tile_ref(knext++);
                 stage_load(pending);
             }
             prefetch_epilogue(cur);
+            __builtin_amdgcn_s_setprio(0);
             STAMP(t1);
 #ifndef ISG_NO_MFMA  // diagnostic build without the k-loop: what the staging / epilogue structure alone takes
             if (cur.valid && cur.live) mainloop();

@@ -292,6 +292,8 @@ int dispatch(const int* va, const int* na, const int* vb, const int* nb, int n, 
 extern "C" int isg_raster_iou(const int32_t* verts_pred, const int32_t* nverts_pred, const int32_t* verts_true,
                               const int32_t* nverts_true, int n, int vmax, int size, int32_t* out_inter,
                               int32_t* out_union, uint8_t* mask_pred, uint8_t* mask_true, void* stream) {
+    ISG_REQUIRE(n >= 0, ISG_EINVAL, "isg_raster_iou: n=%d", n);
+    if (n == 0) return ISG_OK;  // an empty batch has no buffers to speak of
     ISG_REQUIRE(out_inter && out_union, ISG_EINVAL, "isg_raster_iou: null output pointer");
     return dispatch(verts_pred, nverts_pred, verts_true, nverts_true, n, vmax, size, 2, out_inter, out_union,
                     mask_pred, mask_true, stream);

@@ -239,3 +239,13 @@ def test_env_step_kernel_matches_scalar_envs_on_random_actions(end_token):
         assert np.array_equal(rec[1][:, t].cpu().numpy(), acts)
     assert done.any()
     assert int(rec[2].sum()) > 0
+
+
+def test_empty_batch_is_a_no_op():
+    """n = 0: nothing to rasterise, no buffers needed, no error."""
+    from imagesegmentation_amd import util
+    dev = _dev()
+    z3 = torch.zeros([0, 16, 2], dtype=torch.int32, device=dev)
+    z1 = torch.zeros([0], dtype=torch.int32, device=dev)
+    inter, union = util.raster_iou(z3, z1, z3, z1, 28)
+    assert inter.numel() == 0 and union.numel() == 0

@@ -25,6 +25,8 @@ def main():
     from imagesegmentation_amd import _lib
     if "--nomfma" in sys.argv:
         _lib.LIB_PATH = OUT
+    if "--lib" in sys.argv:  # any other variant library (A/B of kernel changes)
+        _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
     import bench
     from imagesegmentation_amd.polyrnn import experiments
     dev = torch.device("cuda:0")

@@ -38,6 +38,9 @@ def main():
     lib.isg_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda:0")
     B, P, F = 64, 224, 16
+    if "--rollout-shape" in sys.argv:  # 2,048 environments at 28 x 28, no gate images (decode / rollout steps)
+        B, P = 2048, 28
+    keep_gates = "--rollout-shape" not in sys.argv
     names = ["issue_prefetch", "k_loop", "stage_store(wait+lds)", "epilogue", "barrier_after_compute",
              "barrier_after_finish", "total", "half_steps"]
     for C, hist in ((33, 1), (16, 0)):
@@ -56,7 +59,8 @@ def main():
         dwh = torch.zeros_like(cell.hidden_to_state_kernel)
         db = torch.zeros_like(cell.bias)
         # wgrad rows: "group" 0 = wave 0, 1 = wave 7; phases: load issue, k-loop, wait + LDS writes, -, barrier
-        for label, fn in (("cell_fwd C=%d" % C, lambda: ops.cell_fwd(x, h, c, packed, gates=gates, hist_points=pts)),
+        for label, fn in (("cell_fwd C=%d" % C, lambda: ops.cell_fwd(x, h, c, packed, gates=gates if keep_gates else None,
+                                                                     save_gates=keep_gates, hist_points=pts)),
                           ("dgrad C=%d" % C, lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs)),
                           ("wgrad C=%d" % C, lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, False,
                                                                hist_points=pts, hist=hist))):
