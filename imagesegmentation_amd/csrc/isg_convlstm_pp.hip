@@ -65,7 +65,12 @@ struct PP {
     static constexpr int PSTRIDE = CPT * 2 + 16;  // LDS bytes per staged pixel (pad spreads banks)
     static constexpr int IN_BYTES = (NPX_ * PSTRIDE + 15) & ~15;
     static constexpr int W_BYTES = NS * MT * 1024;
-    static constexpr int NLOAD = (NPX_ * NCH + 255) / 256;  // staged chunks per thread per tile
+    static constexpr int NCH1 = NCH - NCH0;
+    // staged 16-byte chunks per thread per tile: the chunks of in0 first, then those of in1, each list
+    // rounded up to whole passes of the group's 256 threads so that a pass reads one array only
+    static constexpr int NL0 = (NPX_ * NCH0 + 255) / 256;
+    static constexpr int NL1 = (NPX_ * NCH1 + 255) / 256;
+    static constexpr int NLOAD = NL0 + NL1;
     static constexpr int TAB_FLOATS = NG + 9 * 2 * NG;     // bias + history taps (hist <= 2)
     static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + (MODE == 0 ? TAB_FLOATS * 4 : 0);
 };
@@ -126,6 +131,32 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     uint4 st[K::NLOAD];
     int st_meta[5] = {0x7fffffff, -1, 0, -1, 0};
     unsigned st_inside = 0u;  // bit j: chunk j of this thread lies inside the image
+    // Where chunk j of this thread sits in the halo tile never changes: its LDS byte offset (bits 0-15), halo
+    // row (16-19) and column (20-25), 16 x its chunk index within the pixel (26-30; bits 4-6 once shifted) and
+    // whether it exists at all (31) are worked out once, and a tile only adds its origin.
+    // The widest instantiation has no registers to spare for the table and works the word out again per use.
+    constexpr bool KEEP_INFO = !(C0 == 32 && C1 == 16);
+    auto make_info = [&](int j, int g) {
+        const bool second = j >= K::NL0;
+        const int nch = second ? K::NCH1 : K::NCH0;
+        const int idx = g + 256 * (second ? j - K::NL0 : j);
+        const bool exists = idx < K::NPX_ * nch;
+        const int cidx = exists ? idx : K::NPX_ * nch - 1;
+        const int px = cidx / nch, chl = cidx - px * nch;
+        const int hy = px / HALO_W, hx = px - hy * HALO_W;
+        const unsigned ldso = px * K::PSTRIDE + ((second ? K::NCH0 : 0) + chl) * 16;
+        return ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
+    };
+    unsigned info[KEEP_INFO ? K::NLOAD : 1];
+    if constexpr (KEEP_INFO) {
+#pragma unroll
+        for (int j = 0; j < K::NLOAD; ++j) info[j] = make_info(j, gtid);
+    }
+    auto opaque_gtid = [&]() {
+        int g = gtid;
+        if constexpr (!KEEP_INFO) asm volatile("" : "+v"(g));  // keeps the recomputation from being hoisted
+        return g;
+    };
     auto stage_load = [&](const TileRef& r) {
         if (!r.valid) return;
         st_inside = 0u;
@@ -136,21 +167,24 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             for (int i = 0; i < 4; ++i)
                 if (i < 2 * p.hist) st_meta[1 + i] = p.hist_points[(size_t)r.b * p.hist_bstride + i];
         }
-        int g = gtid;
-        asm volatile("" : "+v"(g));  // recompute the per-chunk coordinates each time: cheaper than keeping
-                                     // 2 * NLOAD loop-invariant registers alive across the k-loop
+        const int row0 = r.b * p.H;
+        const int g = opaque_gtid();
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const int idx = min(g + 256 * j, K::NPX_ * K::NCH - 1);
-            const int px = idx / K::NCH, ch = idx - px * K::NCH;
-            const int hy = px / HALO_W, hx = px - hy * HALO_W;
-            const int gy = r.ty0 + hy - 1, gx = r.tx0 + hx - 1;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) st_inside |= 1u << j;
+            const unsigned inf = KEEP_INFO ? info[KEEP_INFO ? j : 0] : make_info(j, g);
+            const int hy = (inf >> 16) & 15, hx = (inf >> 20) & 63;
+            const int gy = r.ty0 - 1 + hy, gx = r.tx0 - 1 + hx;
+            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) st_inside |= 1u << j;
             const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-            const size_t pixel = ((size_t)r.b * p.H + cy) * p.W + cx;
-            const T* src = ch < K::NCH0 ? static_cast<const T*>(p.in0) + pixel * C0 + ch * 8
-                                        : static_cast<const T*>(p.in1) + pixel * C1 + (ch - K::NCH0) * 8;
-            st[j] = *reinterpret_cast<const uint4*>(src);
+            const unsigned pixel = (unsigned)((row0 + cy) * p.W + cx);
+            const unsigned chunk_bytes = (inf >> 22) & 0x70u;
+            // byte offsets fit 32 bits (checked on the host): a scalar base plus one vector offset per load
+            if (j < K::NL0)
+                st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in0) +
+                                                        (size_t)(pixel * (unsigned)(C0 * 2) + chunk_bytes));
+            else
+                st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in1) +
+                                                        (size_t)(pixel * (unsigned)(C1 * 2) + chunk_bytes));
         }
     };
     auto stage_store = [&](TileRef& r) {
@@ -159,15 +193,13 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.hp[i] = __builtin_amdgcn_readfirstlane(st_meta[1 + i]);
         if (!r.live) return;
-        int g = gtid;
-        asm volatile("" : "+v"(g));
+        const int g = opaque_gtid();
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const int idx = g + 256 * j;
-            const int px = idx / K::NCH, ch = idx - px * K::NCH;
+            const unsigned inf = KEEP_INFO ? info[KEEP_INFO ? j : 0] : make_info(j, g);
             const bool in = (st_inside >> j) & 1u;
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
-            if (idx < K::NPX_ * K::NCH) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = v;
+            if (inf & 0x80000000u) *reinterpret_cast<uint4*>(lds_in + (inf & 0xFFFFu)) = v;
         }
     };
 
@@ -428,6 +460,8 @@ int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     using K = PP<C0, C1, MT, MODE, NPT>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
     if (MODE == 0 && p0.hist > 2) return kNotSupported;
+    // the staging loads address their arrays with 32-bit byte offsets
+    if ((long long)p0.B * p0.H * p0.W * (C0 > C1 ? C0 : C1) * 2 >= (1LL << 32)) return kNotSupported;
     ConvParams p = p0;
     p.tiles_y = (p.H + K::TH_ - 1) / K::TH_;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT>),
