@@ -77,7 +77,7 @@ struct PP {
 
 // EARLY: request the tile after next already in the finish phase (two phases of flight, ahead of the
 // phase's stores) instead of at the start of the compute phase (one phase of flight).  Measured at
-// 224 x 224: better for the 48-channel forward cell, worse for the others.
+// 224 x 224 with the present staging code: no instantiation gains from it, so none is launched with it.
 template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
 __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     using K = PP<C0, C1, MT, MODE, NPT>;
@@ -134,29 +134,19 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     // Where chunk j of this thread sits in the halo tile never changes: its LDS byte offset (bits 0-15), halo
     // row (16-19) and column (20-25), 16 x its chunk index within the pixel (26-30; bits 4-6 once shifted) and
     // whether it exists at all (31) are worked out once, and a tile only adds its origin.
-    // The widest instantiation has no registers to spare for the table and works the word out again per use.
-    constexpr bool KEEP_INFO = !(C0 == 32 && C1 == 16);
-    auto make_info = [&](int j, int g) {
+    unsigned info[K::NLOAD];
+#pragma unroll
+    for (int j = 0; j < K::NLOAD; ++j) {
         const bool second = j >= K::NL0;
         const int nch = second ? K::NCH1 : K::NCH0;
-        const int idx = g + 256 * (second ? j - K::NL0 : j);
+        const int idx = gtid + 256 * (second ? j - K::NL0 : j);
         const bool exists = idx < K::NPX_ * nch;
         const int cidx = exists ? idx : K::NPX_ * nch - 1;
         const int px = cidx / nch, chl = cidx - px * nch;
         const int hy = px / HALO_W, hx = px - hy * HALO_W;
         const unsigned ldso = px * K::PSTRIDE + ((second ? K::NCH0 : 0) + chl) * 16;
-        return ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
-    };
-    unsigned info[KEEP_INFO ? K::NLOAD : 1];
-    if constexpr (KEEP_INFO) {
-#pragma unroll
-        for (int j = 0; j < K::NLOAD; ++j) info[j] = make_info(j, gtid);
+        info[j] = ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
     }
-    auto opaque_gtid = [&]() {
-        int g = gtid;
-        if constexpr (!KEEP_INFO) asm volatile("" : "+v"(g));  // keeps the recomputation from being hoisted
-        return g;
-    };
     auto stage_load = [&](const TileRef& r) {
         if (!r.valid) return;
         st_inside = 0u;
@@ -168,10 +158,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 if (i < 2 * p.hist) st_meta[1 + i] = p.hist_points[(size_t)r.b * p.hist_bstride + i];
         }
         const int row0 = r.b * p.H;
-        const int g = opaque_gtid();
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const unsigned inf = KEEP_INFO ? info[KEEP_INFO ? j : 0] : make_info(j, g);
+            const unsigned inf = info[j];
             const int hy = (inf >> 16) & 15, hx = (inf >> 20) & 63;
             const int gy = r.ty0 - 1 + hy, gx = r.tx0 - 1 + hx;
             if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) st_inside |= 1u << j;
@@ -193,10 +182,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.hp[i] = __builtin_amdgcn_readfirstlane(st_meta[1 + i]);
         if (!r.live) return;
-        const int g = opaque_gtid();
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const unsigned inf = KEEP_INFO ? info[KEEP_INFO ? j : 0] : make_info(j, g);
+            const unsigned inf = info[j];
             const bool in = (st_inside >> j) & 1u;
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
             if (inf & 0x80000000u) *reinterpret_cast<uint4*>(lds_in + (inf & 0xFFFFu)) = v;
@@ -819,7 +807,7 @@ namespace isgc {
 int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream_t stream) {
     if (mode == 0) {
         if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, false>(p, num_cus, stream);
-        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, true>(p, num_cus, stream);
+        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, false>(p, num_cus, stream);
         return kNotSupported;
     }
     if (p.c0 == NG && p.c1 == 0 && mt == 1) return launch_pp<NG, 0, 1, 1, false>(p, num_cus, stream);
