@@ -113,7 +113,7 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         gates = torch.empty([B, P, P, F, 4], dtype=dt, device=dev)
         dy = torch.empty_like(gates)
         dh = torch.randn([B, P, P, F], device=dev).to(dt)
-        dc = torch.randn([B, P, P, F], device=dev)
+        dc = torch.randn([B, P, P, F], device=dev).to(dt)  # carried in the activation dtype, as in the train step
         dcp = torch.empty_like(dc)
         dx = torch.empty([B, P, P, cs], dtype=dt, device=dev)
         dhp = torch.empty_like(h)
@@ -129,7 +129,7 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
             ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts), flops,
              px * (x_b + h_b + c_b + h_b + c_b + g_b)),
             ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
-             0.0, px * (2 * g_b + 2 * h_b + 4 * c_b)),
+             0.0, px * (2 * g_b + 2 * h_b + 2 * c_b + 2 * h_b)),  # the dc carry is stored like dh
             ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, px * (g_b + x_b + h_b)),
             ("wgrad", lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, accumulate=False, hist_points=pts, hist=hist),
              flops, px * (x_b + h_b + g_b)),

@@ -414,8 +414,9 @@ class _SequenceFunction(torch.autograd.Function):
         dc_state, dh_state = [], []
         for l in range(L):
             dc, dh = d_final[2 * l], d_final[2 * l + 1]
-            dc_state.append(dc.to(torch.float32).clone().contiguous() if dc is not None else
-                            torch.zeros([B, H, W, F], dtype=torch.float32, device=dev))
+            # the cell-state gradient is carried between steps in the activation dtype, like dL/dh
+            dc_state.append(dc.to(dt).clone().contiguous() if dc is not None else
+                            torch.zeros([B, H, W, F], dtype=dt, device=dev))
             dh_state.append(dh.to(dt).clone().contiguous() if dh is not None else
                             torch.zeros([B, H, W, F], dtype=dt, device=dev))
         grads = []

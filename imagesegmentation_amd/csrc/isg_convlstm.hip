@@ -230,8 +230,8 @@ struct PointwiseParams {
     int pool;              // > 1: dh_above is on the grid pooled by pool x pool windows (gradient of an average pool)
     int W;
     const void* dh_state;  // grad of h as carried STATE [B,H,W,F], or null
-    const float* dc_state; // [B,H,W,F] or null
-    float* dc_prev;        // [B,H,W,F] (may alias dc_state)
+    const void* dc_state;  // [B,H,W,F] or null, float or bf16 (the kernel's DC type)
+    void* dc_prev;         // [B,H,W,F], same type (may alias dc_state)
     void* dy;              // [B,H,W,F,4] pre-activation grads, (channel, gate) order
     const int* durations;
     int t, B, HW;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void load_run(const __bf16* src, float (&v)[CPT]) {
 // One thread takes the channels whose four gate values fill 16 bytes (2 for bf16, 1 for float), so
 // that every load and store of a wave covers whole, contiguous cache lines: a narrower split makes
 // the dy stores partial-sector writes, which cost twice the HBM write traffic.
-template <typename T>
+template <typename T, typename DC>
 __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams p) {
     constexpr int CPT = sizeof(T) == 2 ? 2 : 1;  // channels per thread
     constexpr int TPP = F_ / CPT;                // threads per pixel
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams
         float dc[CPT], gv[4 * CPT], out[4 * CPT], dcp[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) dc[k] = 0.0f;
-        if (p.dc_state) load_run<CPT>(p.dc_state + so, dc);
+        if (p.dc_state) load_run<CPT>(static_cast<const DC*>(p.dc_state) + so, dc);
         T* dy = static_cast<T*>(p.dy) + (size_t)pixel * NG + q * 4 * CPT;
         if (!live) {
 #pragma unroll
@@ -335,12 +335,18 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(PointwiseParams
                 dcp[k] = dct * fg;
             }
         }
+        DC* dcd = static_cast<DC*>(p.dc_prev) + so;
         if constexpr (CPT == 2) {
             store8(dy, out);
-            *reinterpret_cast<float2*>(p.dc_prev + so) = float2{dcp[0], dcp[1]};
+            if constexpr (sizeof(DC) == 4) {
+                *reinterpret_cast<float2*>(dcd) = float2{dcp[0], dcp[1]};
+            } else {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<bf16x2*>(dcd) = bf16x2{(__bf16)dcp[0], (__bf16)dcp[1]};
+            }
         } else {
             store4(dy, reinterpret_cast<const float(&)[4]>(out));
-            p.dc_prev[so] = dcp[0];
+            dcd[0] = (DC)dcp[0];
         }
     }
 }
@@ -712,12 +718,14 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const fl
 
 extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur,
                                           const void* dh_above, long long dh_above_batch_stride, int dh_above_pool,
-                                          const void* dh_state, const float* dc_state, int B, int H, int W, int F,
-                                          int dtype, const int32_t* durations, int t, void* dy, float* dc_prev,
-                                          void* stream) {
+                                          const void* dh_state, const void* dc_state, int dc_dtype, int B, int H,
+                                          int W, int F, int dtype, const int32_t* durations, int t, void* dy,
+                                          void* dc_prev, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(gates && c_prev && c_cur && dy && dc_prev, ISG_EINVAL, "isg_convlstm_pointwise_bwd: null pointer");
     ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_convlstm_pointwise_bwd: dtype %d", dtype);
+    ISG_REQUIRE(dc_dtype == ISG_F32 || dc_dtype == ISG_BF16, ISG_EDTYPE, "isg_convlstm_pointwise_bwd: dc_dtype %d",
+                dc_dtype);
     PointwiseParams p = {};
     p.gates = gates, p.c_prev = c_prev, p.c_cur = c_cur;
     ISG_REQUIRE(dh_above_pool >= 1 && H % dh_above_pool == 0 && W % dh_above_pool == 0, ISG_EINVAL,
@@ -728,10 +736,14 @@ extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev
     const long long total = (long long)B * H * W * (dtype == ISG_F32 ? F_ : F_ / 2);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ISG_F32)
-        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+    if (dtype == ISG_F32 && dc_dtype == ISG_F32)
+        hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, s, p);
+    else if (dtype == ISG_F32)
+        hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, s, p);
+    else if (dc_dtype == ISG_F32)
+        hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, s, p);
     return isg::check_launch("lstm_pointwise_bwd_kernel");
 }
 

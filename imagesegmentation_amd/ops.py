@@ -151,15 +151,18 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
 @_timed("pointwise_bwd")
 def pointwise_bwd(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, durations=None, t=0,
                   dy=None, dc_prev=None, pool=1):
-    """Gate backward. Returns (dy [B,H,W,F,4], dc_prev float32 [B,H,W,F]).  ``pool`` = k > 1: dh_above is
-    the gradient of the k x k average-pooled output, [H/k, W/k, F] per sample."""
+    """Gate backward. Returns (dy [B,H,W,F,4], dc_prev [B,H,W,F]).  ``pool`` = k > 1: dh_above is
+    the gradient of the k x k average-pooled output, [H/k, W/k, F] per sample.  The carried cell-state
+    gradient (dc_state in, dc_prev out) is float32 or bfloat16, both the same; float32 when neither is given."""
     B, H, W, F, _ = gates.shape
     dy = torch.empty_like(gates) if dy is None else dy
-    dc_prev = torch.empty([B, H, W, F], dtype=torch.float32, device=gates.device) if dc_prev is None else dc_prev
+    dc_dtype = dc_prev.dtype if dc_prev is not None else (dc_state.dtype if dc_state is not None else torch.float32)
+    dc_prev = torch.empty([B, H, W, F], dtype=dc_dtype, device=gates.device) if dc_prev is None else dc_prev
+    assert dc_prev.dtype == dc_dtype and (dc_state is None or dc_state.dtype == dc_dtype)
     rc = _lib.lib().isg_convlstm_pointwise_bwd(
         _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(c_cur), dh_above.data_ptr() if dh_above is not None else None,
-        int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), B, H, W, F,
-        dtype_code(gates.dtype),
+        int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), dtype_code(dc_dtype),
+        B, H, W, F, dtype_code(gates.dtype),
         _lib.ptr(durations), int(t), _lib.ptr(dy), _lib.ptr(dc_prev), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_pointwise_bwd")
     return dy, dc_prev

@@ -145,11 +145,13 @@ int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev
  * reference convLSTM.py:40-43 that tf.gradients derives (reference polyrnn/Model.py:108).
  * dh_above_pool = 1: dh_above is [H][W][F] per sample.  dh_above_pool = k > 1: the emitted output went
  * through a k x k average pool (isg_avgpool_fwd) and dh_above is the gradient of the POOLED tensor,
- * [H/k][W/k][F] per sample; each pixel takes 1/k^2 of its window's value, never materialised. */
+ * [H/k][W/k][F] per sample; each pixel takes 1/k^2 of its window's value, never materialised.
+ * dc_dtype = storage type of the carried cell-state gradient (dc_state and dc_prev): ISG_F32, or ISG_BF16
+ * to carry it like dL/dh already is in a bf16 run (64 fewer bytes per pixel-step; arithmetic stays float). */
 int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
                                long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
-                               const float* dc_state, int B, int H, int W, int F, int dtype,
-                               const int32_t* durations, int t, void* dy, float* dc_prev, void* stream);
+                               const void* dc_state, int dc_dtype, int B, int H, int W, int F, int dtype,
+                               const int32_t* durations, int t, void* dy, void* dc_prev, void* stream);
 
 /* Backward, step 2 (data gradient of reference convLSTM.py:36-37): dx (optional; first
  * dx_channels channels, pixel stride dx_channel_stride, += when dx_accumulate) and dh_prev
