@@ -534,7 +534,7 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
             import numpy as np
             host = np.asarray(sequence_length)
             t_run = int(host.max()) if host.size else 0
-            durations_dev = torch.as_tensor(host.astype(np.int32), device=dev)
+            durations_dev = ops.upload(host.astype(np.int32), dev)
         t_run = max(0, min(t_run, T))
     wide = any(c._filters != ops.F_HIDDEN for c in multi.cells)
     if initial_state is None:

@@ -11,6 +11,24 @@ from . import _lib
 F_HIDDEN = 16  # the kernels are specialised for the reference's 16 hidden channels
 
 
+def upload(array, device, dtype=None):
+    """Host array -> device tensor without stalling the host: small arrays (sequence lengths, targets, vertex
+    points) go through pinned memory as an asynchronous copy, so the launches queued behind them keep flowing
+    while the GPU is still busy with earlier work.  A pageable copy would block until the stream drains."""
+    import numpy as np
+    arr = np.ascontiguousarray(np.asarray(array))
+    device = torch.device(device)
+    try:
+        t = torch.from_numpy(arr)
+    except TypeError:  # dtypes torch has no name for (uint16, uint32, ...)
+        t = torch.as_tensor(arr.astype(np.int64 if arr.dtype.kind in "ui" else np.float64))
+    if device.type == "cuda" and 0 < t.numel() * t.element_size() <= (1 << 20):
+        t = t.pin_memory().to(device, non_blocking=True)
+    else:
+        t = t.to(device)
+    return t if dtype is None else t.to(dtype)
+
+
 def dtype_code(dtype):
     if dtype == torch.float32:
         return 0

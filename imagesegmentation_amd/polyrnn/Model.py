@@ -255,7 +255,7 @@ class Model:
     def _to_dev(self, a, dtype):
         if torch.is_tensor(a):
             return a.to(device=self.device, dtype=dtype)
-        return torch.as_tensor(np.asarray(a), device=self.device).to(dtype)
+        return ops.upload(a, self.device, dtype)
 
     def _sequence_input(self, features, histories):
         """histories: dense [B,T,P,P,hist] (the reference's feed) or int points [B,T,hist,2]."""
