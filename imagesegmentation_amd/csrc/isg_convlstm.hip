@@ -558,28 +558,37 @@ __global__ void hist_table_kernel(const float* __restrict__ w_x, int C, int hist
 }
 
 // dw_x[tap][C + i][:] (+)= sum over live samples of dY at the one pixel that tap reaches from the point
+constexpr int kHistGroups = 16;  // sample groups per workgroup
 template <typename T>
-__global__ __launch_bounds__(4 * NG) void hist_wgrad_kernel(const T* __restrict__ dy, const int* __restrict__ pts,
-                                                            long long pts_bstride, int hist, int B, int H, int W, int C,
-                                                            const int* __restrict__ durations, int t, int accumulate,
-                                                            float* __restrict__ dw_x) {
-    __shared__ float red[4][NG];
+__global__ __launch_bounds__(kHistGroups * NG) void hist_wgrad_kernel(const T* __restrict__ dy,
+                                                                     const int* __restrict__ pts, long long pts_bstride,
+                                                                     int hist, int B, int H, int W, int C,
+                                                                     const int* __restrict__ durations, int t,
+                                                                     int accumulate, float* __restrict__ dw_x) {
+    __shared__ float red[kHistGroups][NG];
     const int tap = blockIdx.x / hist, i = blockIdx.x - tap * hist;
     const int k = threadIdx.x & (NG - 1);  // dY channel, (channel, gate) order
-    const int sg = threadIdx.x / NG;       // the samples are dealt to 4 groups of threads
+    const int sg = threadIdx.x / NG;       // the samples are dealt to kHistGroups groups of threads
     const int ty = tap / 3, tx = tap - ty * 3;
     float sum = 0.0f;
-    for (int b = sg; b < B; b += 4) {
-        if (durations != nullptr && t >= durations[b]) continue;
+    // every load of a sample is unconditional (a masked sample reads element 0 and adds nothing), so the
+    // unrolled loop keeps four samples' dependent chains (length, point, dY) in flight at once
+#pragma unroll 4
+    for (int b = sg; b < B; b += kHistGroups) {
+        const bool live = durations == nullptr || t < durations[b];
         const int px = pts[(size_t)b * pts_bstride + 2 * i], py = pts[(size_t)b * pts_bstride + 2 * i + 1];
         const int gy = py - ty + 1, gx = px - tx + 1;
-        if (px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            sum += (float)dy[(((size_t)b * H + gy) * W + gx) * NG + k];
+        const bool hit = live && px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t at = hit ? (((size_t)b * H + gy) * W + gx) * NG + k : (size_t)k;
+        const float v = (float)dy[at];
+        sum += hit ? v : 0.0f;
     }
     red[sg][k] = sum;
     __syncthreads();
     if (sg == 0) {
-        sum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        sum = 0.0f;
+#pragma unroll
+        for (int g = 0; g < kHistGroups; ++g) sum += red[g][k];
         float* dst = dw_x + ((size_t)tap * (C + hist) + C + i) * NG + (k & 3) * F_ + (k >> 2);
         *dst = accumulate ? *dst + sum : sum;
     }
@@ -871,10 +880,10 @@ extern "C" int isg_convlstm_wgrad(const void* x, const void* h_prev, const void*
     if (hist > 0) {
         ISG_REQUIRE(hist_points, ISG_EINVAL, "isg_convlstm_wgrad: history points are needed when hist > 0");
         if (dtype == ISG_F32)
-            hipLaunchKernelGGL(hist_wgrad_kernel<float>, dim3(9 * hist), dim3(4 * NG), 0, s, static_cast<const float*>(dy),
+            hipLaunchKernelGGL(hist_wgrad_kernel<float>, dim3(9 * hist), dim3(kHistGroups * NG), 0, s, static_cast<const float*>(dy),
                                hist_points, hist_batch_stride, hist, B, H, W, C, durations, t, accumulate, dw_x);
         else
-            hipLaunchKernelGGL(hist_wgrad_kernel<__bf16>, dim3(9 * hist), dim3(4 * NG), 0, s,
+            hipLaunchKernelGGL(hist_wgrad_kernel<__bf16>, dim3(9 * hist), dim3(kHistGroups * NG), 0, s,
                                static_cast<const __bf16*>(dy), hist_points, hist_batch_stride, hist, B, H, W, C,
                                durations, t, accumulate, dw_x);
         rc = isg::check_launch("hist_wgrad_kernel");

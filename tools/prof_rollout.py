@@ -25,17 +25,15 @@ def run():
     ds = data.PolygonDataset.synthetic(64, image_size=28, prediction_size=28, max_timesteps=10, history_length=2,
                                        seed=1, end_token=True)
     pol = ExperimentPolicyEstimator(28, 28, max_timesteps=10, end_token=True, compute_dtype=torch.bfloat16, device=dev)
-    runner = BatchedReinforce(pol, ds, N)
-    idx = np.random.RandomState(0).randint(0, len(ds), [N])
-    images = ds._images[idx]
-    polygons = [ds._vertices[i] for i in idx]
-    runner.rollout(images, polygons)
+    runner = BatchedReinforce(pol, ds, N, device_pool=True)
+    fn = runner.step if "--update" in sys.argv else runner.rollout  # --update: rollout + policy update
+    fn()
     torch.cuda.synchronize()
     for _ in range(3):
         t0 = time.perf_counter()
-        runner.rollout(images, polygons)
+        fn()
         torch.cuda.synchronize()
-        print("rollout ms %.3f" % ((time.perf_counter() - t0) * 1e3))
+        print("%s ms %.3f" % (fn.__name__, (time.perf_counter() - t0) * 1e3))
 
 
 def summarize(path):
@@ -58,4 +56,4 @@ def summarize(path):
 
 
 if __name__ == "__main__":
-    summarize(sys.argv[1]) if len(sys.argv) > 1 else run()
+    summarize(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else run()
