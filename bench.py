@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="keep MIOpen's immediate-mode pick for the encoder convs instead of letting it time its solvers "
                          "during warm-up")
-    ap.add_argument("--a3c-envs", type=int, default=256, help="actor-critic environments per GPU (0 = skip)")
+    ap.add_argument("--a3c-envs", type=int, default=1024, help="actor-critic environments per GPU (0 = skip)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -203,8 +203,8 @@ def bench_a3c(n_envs, steps, device, rank, dtype):
     t0 = time.perf_counter()
     env_steps = 0
     for _ in range(steps):
-        batch = trainer.process(images, polygons)
-        env_steps += int(batch["lengths"].sum())
+        trainer.process(images, polygons)
+        env_steps += trainer.last_env_steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {"envs": n_envs, "size": 32, "filters": 32, "env_steps_per_s": env_steps / el, "ms_per_update": el / steps * 1e3,

@@ -218,15 +218,15 @@ class A3C:
         rewards = torch.zeros([N, T], dtype=torch.float64, device=dev)
         lengths = torch.zeros([N], dtype=torch.int32, device=dev)
         for t in range(T):
+            # no "is anyone still running" question to the host: a finished environment ignores its action and
+            # its later steps fall outside its length
             active = ~env.done
-            if not bool(active.any()):
-                break
             obs[:, t] = state
             a, v, c, h = pi.act(state, c, h)
             actions[:, t], values[:, t] = a, v
             lengths += active.to(torch.int32)
             xy = torch.stack([a // P, a % P], dim=1)
-            state, reward, _ = env.step(xy)
+            state, reward, _ = env.step(xy, host_sync=False)
             rewards[:, t] = reward
         return dict(si=obs, a=actions, values=values, rewards=rewards, lengths=lengths, terminal=env.done.clone())
 
@@ -242,11 +242,15 @@ class A3C:
                                r.reshape(-1), live.reshape(-1))
         (loss / N).backward()
         norm = self.opt.step()
-        self.global_step += int(batch["lengths"].sum())
+        # one device-to-host copy for all the scalars of the update
+        total = batch["lengths"].sum().double()
+        stats = torch.stack([total, loss.detach().double(), norm.detach().double().reshape(()),
+                             parts["pi_loss"].detach().double(), parts["vf_loss"].detach().double(),
+                             parts["entropy"].detach().double(), batch["rewards"].sum(dim=1).mean().double()]).tolist()
+        self.global_step += int(stats[0])
         self.local_steps += 1
-        bs = float(batch["lengths"].sum().clamp(min=1))
-        self.last = dict(loss=float(loss) / N, grad_global_norm=float(norm),
-                         policy_loss=float(parts["pi_loss"]) / bs, value_loss=float(parts["vf_loss"]) / bs,
-                         entropy=float(parts["entropy"]) / bs,
-                         episode_reward=float(batch["rewards"].sum(dim=1).mean()))
+        bs = max(stats[0], 1.0)
+        self.last = dict(loss=stats[1] / N, grad_global_norm=stats[2], policy_loss=stats[3] / bs,
+                         value_loss=stats[4] / bs, entropy=stats[5] / bs, episode_reward=stats[6])
+        self.last_env_steps = int(stats[0])
         return batch

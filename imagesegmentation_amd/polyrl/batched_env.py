@@ -149,8 +149,10 @@ class BatchedPolygonEnv:
         _lib.check(rc, "isg_env_step")
         self.steps_taken += 1
 
-    def step(self, actions, compute_reward=True, render=True, record=None, t=0):
+    def step(self, actions, compute_reward=True, render=True, record=None, t=0, host_sync=True):
         """actions: int tensor [N, 2] of (x, y).  Returns (state, reward float64 [N], done bool [N]).
+        ``host_sync=False``: the terminal IoU is evaluated for every environment in one launch and masked on the
+        device, instead of asking the host which environments finished - same rewards, no round trip.
 
         One ``isg_env_step`` launch updates every environment.  With ``compute_reward=False`` the
         terminal IoU is not evaluated in this call (reward is 0); use ``terminal_rewards()`` once all
@@ -166,7 +168,12 @@ class BatchedPolygonEnv:
         if render and self.hist > 0:
             self._render_history()
         reward = torch.zeros([n], dtype=torch.float64, device=self.device)
-        if compute_reward:
+        if compute_reward and not host_sync:
+            terminal = self.done & ~before
+            inter, union = util.raster_iou(self.predicted_vertices, self.num_predicted, self.vertices,
+                                           self.num_vertices, self.size)
+            reward = torch.where(terminal, inter.double() / union.double(), reward)
+        elif compute_reward:
             terminal = self.done & ~before
             if bool(terminal.any()):
                 idx = terminal.nonzero(as_tuple=True)[0]
