@@ -198,6 +198,10 @@ def bench_a3c(n_envs, steps, device, rank, dtype):
     polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
     env = BatchedPolygonEnv(ds, n_envs, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=device)
     trainer = a3c.A3C(env, compute_dtype=dtype, seed=0)
+    # this leg's encoder runs on the vendor convolution at shapes nothing else uses: its exhaustive solver search
+    # would take minutes here, the library's immediate choice takes none
+    find = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
     trainer.process(images, polygons)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -207,6 +211,7 @@ def bench_a3c(n_envs, steps, device, rank, dtype):
         env_steps += trainer.last_env_steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    torch.backends.cudnn.benchmark = find
     return {"envs": n_envs, "size": 32, "filters": 32, "env_steps_per_s": env_steps / el, "ms_per_update": el / steps * 1e3,
             "loss": trainer.last["loss"]}
 
@@ -320,6 +325,15 @@ def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
     return res
 
 
+def note(msg):
+    """Progress on stderr (stdout carries the one JSON line): a long silent run looks hung to a supervisor."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main():
     args = parse()
     if os.environ.get("ISG_BENCH_WATCHDOG"):  # dump every thread's stack and exit if the run takes this long
@@ -367,8 +381,10 @@ def main():
     def step():
         return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
 
+    note("model and batch ready; warm-up (the first step includes the convolution solver search)")
     for _ in range(args.warmup):
         step()
+    note("timing %d training steps" % args.steps)
 
     def fence():
         torch.cuda.synchronize()
@@ -388,6 +404,7 @@ def main():
         elapsed = float(tmax.item())
     seqs = args.batch * world * args.steps
 
+    note("training leg done: %.3f ms/step; rasteriser leg (with its CPU baseline unless disabled)" % (elapsed / args.steps * 1e3))
     # ---- rasteriser / IoU leg (sharded rollouts, no collective) ------------------------------
     raster = bench_raster(args.rollouts, size, max(args.steps, 5), args.warmup, device, rank,
                           do_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
@@ -400,6 +417,7 @@ def main():
 
     rl = None
     if args.rl_envs > 0:
+        note("REINFORCE leg")
         rl = bench_reinforce(args.rl_envs, 3, device, rank, dtype)
         if world > 1:
             r = torch.tensor([rl["ms_per_step"]], device=device, dtype=torch.float64)
@@ -411,6 +429,7 @@ def main():
 
     ac = None
     if args.a3c_envs > 0:
+        note("actor-critic leg")
         ac = bench_a3c(args.a3c_envs, 2, device, rank, dtype)
         if world > 1:
             r = torch.tensor([ac["env_steps_per_s"]], device=device, dtype=torch.float64)
@@ -420,6 +439,7 @@ def main():
 
     kernels, roofline, cpu = None, None, None
     if rank == 0 and not args.no_kernel_timing:
+        note("per-kernel timing")
         from imagesegmentation_amd import ops
         with ops.timeline() as tl:  # two more steps, outside the timed region, with events around every cell launch
             for _ in range(2):
@@ -450,6 +470,7 @@ def main():
                     "kernel": sym if len(members) > 1 else dom["kernel"], "launches_per_step": len(members) * T,
                     "ms_per_launch": ms, "algorithmic_bytes": nbytes, "flops": flops}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("CPU baseline of the training step (bounded sample)")
         cpu = cpu_baseline_convlstm(model, batch, size, T, hist, head_size)
 
     if rank == 0:

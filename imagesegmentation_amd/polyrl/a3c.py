@@ -28,6 +28,7 @@ import torch.nn.functional as F
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, dynamic_rnn, glorot_uniform_
 from ..optim import FlatAdam
 from ..polyrnn import decode
+from ..polyrnn.Model import conv2d_same_relu
 
 
 def discount(x, gamma):
@@ -154,12 +155,12 @@ class LSTMPolicy:
 
     def _encode(self, x):
         # [R, H, W, C] -> [R, H, W, 32]
+        # the same layer routine as the polygon-RNN encoder: 32 -> 32 layers run on the conv32 kernels in bf16
         dt = self.compute_dtype
-        y = x.to(dt).permute(0, 3, 1, 2)
+        y = x.to(dt).contiguous()
         for w, b in self.convs:
-            wk = w.to(dt).permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
-            y = F.relu(F.conv2d(y, wk, b.to(dt), padding=1))
-        return y.permute(0, 2, 3, 1).contiguous()
+            y = conv2d_same_relu(y, w, b, dt)
+        return y.contiguous()
 
     def forward(self, x, state):
         """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out."""
