@@ -4,11 +4,17 @@ Every function enqueues HIP kernels on torch's current stream and returns torch 
 CPU path.  Activations are NHWC, float32 or bfloat16; the cell state and parameter gradients are
 float32.
 """
+import os
+
 import torch
 
 from . import _lib
 
 F_HIDDEN = 16  # the kernels are specialised for the reference's 16 hidden channels
+
+
+# ISG_BLOCKING_UPLOADS=1 restores plain pageable copies (a debugging aid: it throttles the host to the GPU's pace)
+_BLOCKING_UPLOADS = bool(os.environ.get("ISG_BLOCKING_UPLOADS"))
 
 
 def upload(array, device, dtype=None):
@@ -22,7 +28,7 @@ def upload(array, device, dtype=None):
         t = torch.from_numpy(arr)
     except TypeError:  # dtypes torch has no name for (uint16, uint32, ...)
         t = torch.as_tensor(arr.astype(np.int64 if arr.dtype.kind in "ui" else np.float64))
-    if device.type == "cuda" and 0 < t.numel() * t.element_size() <= (1 << 20):
+    if device.type == "cuda" and 0 < t.numel() * t.element_size() <= (1 << 20) and not _BLOCKING_UPLOADS:
         t = t.pin_memory().to(device, non_blocking=True)
     else:
         t = t.to(device)
