@@ -39,6 +39,55 @@ def allreduce_gradients_(flat, group=None, average=True):
     return flat
 
 
+class EarlyTailReduce:
+    """The same all-reduce in two pieces, so that most of it hides behind the backward pass.
+
+    ``flat`` is the gradient bucket, ``tail_params`` the parameters whose gradients are views of
+    ``flat[offset:]`` and are complete EARLY in a backward pass (the dense head: 99 % of the bytes, first to
+    finish).  While ``arm()``-ed, the moment the last of them has its gradient the tail is all-reduced
+    asynchronously (RCCL on its own stream, next to the recurrence's backward kernels); ``finish()`` after
+    the backward reduces the remaining head of the bucket, waits for the tail and averages.  Every rank
+    issues the two collectives in the same order.  Not armed, or with one rank, nothing happens early and
+    ``finish()`` is ``allreduce_gradients_``."""
+
+    def __init__(self, flat, tail_params, offset, group=None):
+        self.flat, self.offset, self.group = flat, int(offset), group
+        self._n = len(tail_params)
+        self._seen = 0
+        self._work = None
+        self.armed = False
+        self.early_launches = 0  # how many times the tail went out from the hook (tests, diagnostics)
+        for p in tail_params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def arm(self):
+        self.armed, self._seen, self._work = True, 0, None
+
+    def _on_grad(self, _param):
+        if not self.armed or world_size(self.group) == 1:
+            return
+        self._seen += 1
+        if self._seen == self._n:
+            self._work = dist.all_reduce(self.flat[self.offset:], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True)
+            self.early_launches += 1
+
+    def finish(self, average=True):
+        was_armed, self.armed = self.armed, False
+        work, self._work = self._work, None
+        world = world_size(self.group)
+        if world == 1:
+            return self.flat
+        if not was_armed or work is None:
+            return allreduce_gradients_(self.flat, self.group, average)
+        if self.offset > 0:
+            dist.all_reduce(self.flat[:self.offset], op=dist.ReduceOp.SUM, group=self.group)
+        work.wait()
+        if average:
+            self.flat.div_(world)
+        return self.flat
+
+
 def allreduce_max(value, device, group=None):
     """Max of a python float over ranks (timing)."""
     if world_size(group) == 1:

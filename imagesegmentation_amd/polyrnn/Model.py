@@ -193,9 +193,17 @@ class Model:
         n = sum(p.numel() for p in self.trainable_variables)
         self._flat_grad = torch.zeros([n], dtype=torch.float32, device=self.device)
         off = 0
+        head_at = None
         for p in self.trainable_variables:
+            if p is self.dense_kernel:
+                head_at = off
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
+        # the dense head (kernel, then bias) closes the bucket: its share of the all-reduce starts as soon as
+        # its gradient exists, under the recurrence's backward pass
+        assert head_at is not None and head_at + self.dense_kernel.numel() + self.dense_bias.numel() == n
+        self._early_reduce = parallel.EarlyTailReduce(self._flat_grad, [self.dense_kernel, self.dense_bias], head_at,
+                                                      process_group)
         self._events = None
         # values of the last evaluation (graph nodes in the reference)
         self.prediction_logits = None
@@ -328,7 +336,7 @@ class Model:
         clip of the reduced gradient, TensorFlow-form Adam."""
         flat = self._flat_grad
         if all_reduce:
-            parallel.allreduce_gradients_(flat, self.process_group, average=average)
+            self._early_reduce.finish(average=average)
         norm = flat.norm()
         if clip:  # tf.clip_by_global_norm(grads, 1.0): scale = clip / max(norm, clip)
             flat.mul_(1.0 / torch.clamp(norm, min=1.0))
@@ -352,6 +360,7 @@ class Model:
         self._flat_grad.zero_()
         logits, _ = self.forward(images, durations, histories)
         loss, metrics = self._loss_and_metrics(logits, durations, targets)
+        self._early_reduce.arm()
         loss.backward()
         self._apply_gradients()
         self.loss = loss.detach()

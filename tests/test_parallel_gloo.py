@@ -67,6 +67,34 @@ def _adam_case(grad_sets, all_reduce):
     return torch.cat([p.detach().reshape(-1) for p in params]).numpy()
 
 
+def _early_tail_case(rank, reduce=True):
+    """A two-layer toy net whose LAST layer closes the flat bucket: armed, its gradient is reduced from the
+    autograd hook; the result must be the plain average over ranks (and a second, unarmed pass the plain sum)."""
+    from imagesegmentation_amd import parallel
+    g = torch.Generator().manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(5, 4, generator=g))
+    b = torch.nn.Parameter(torch.randn(4, 3, generator=g))
+    c = torch.nn.Parameter(torch.randn(3, generator=g))
+    flat = torch.zeros([a.numel() + b.numel() + c.numel()])
+    off = 0
+    for p in (a, b, c):
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    early = parallel.EarlyTailReduce(flat, [b, c], a.numel())
+    x = torch.randn(7, 5, generator=torch.Generator().manual_seed(50 + rank))
+    outs = []
+    for armed, average in ((True, True), (False, False)):
+        flat.zero_()
+        if armed:
+            early.arm()
+        (torch.tanh(x @ a) @ b + c).square().sum().backward()
+        if reduce:
+            early.finish(average=average)
+        outs.append(flat.clone().numpy())
+    assert early.early_launches == (1 if reduce and dist.is_initialized() else 0)
+    return outs
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -85,6 +113,7 @@ def _worker(rank, world, port, ret):
         flat = _flat_grads(tp)
         parallel.allreduce_gradients_(flat, average=(mode == "mean"))
         out[mode] = flat.numpy()
+    out["early"] = _early_tail_case(rank)
     out["max"] = parallel.allreduce_max(float(rank + 1), "cpu")
     out["adam"] = _adam_case([_rank_grads(rank)], all_reduce=True)
     ret[rank] = out
@@ -107,6 +136,9 @@ def test_two_rank_gradients_match_single_process():
     for rank in (0, 1):
         for mode in ("mean", "episode_sum"):
             assert np.allclose(ret[rank][mode], ref[mode], rtol=1e-10, atol=1e-12), (rank, mode)
+        locals_ = [_early_tail_case(r, reduce=False) for r in (0, 1)]
+        assert np.allclose(ret[rank]["early"][0], (locals_[0][0] + locals_[1][0]) / 2, rtol=1e-6, atol=1e-6)
+        assert np.allclose(ret[rank]["early"][1], locals_[0][1] + locals_[1][1], rtol=1e-6, atol=1e-6)
         assert ret[rank]["max"] == 2.0
         assert np.allclose(ret[rank]["adam"], _adam_case([_rank_grads(0), _rank_grads(1)], all_reduce=False),
                            rtol=1e-6, atol=1e-7)
