@@ -241,7 +241,8 @@ struct PointwiseParams {
 template <int CPT>
 __device__ __forceinline__ void load_run(const float* src, float (&v)[CPT]) {
     if constexpr (CPT == 2) {
-        const float2 x = *reinterpret_cast<const float2*>(src);
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v x = *reinterpret_cast<const f32x2v*>(src);
         v[0] = x.x, v[1] = x.y;
     } else {
         v[0] = src[0];
@@ -743,7 +744,9 @@ extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev
     p.dh_state = dh_state, p.dc_state = dc_state, p.dc_prev = dc_prev, p.dy = dy;
     p.durations = durations, p.t = t, p.B = B, p.HW = H * W;
     const long long total = (long long)B * H * W * (dtype == ISG_F32 ? F_ : F_ / 2);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    // grid-stride beyond 65,536 workgroups (measured at 100 k workgroups' worth of pixels: 16 k workgroups 3.5 %
+    // slower, one workgroup per 256 items 1 % slower; non-temporal loads and stores 7 % slower)
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32 && dc_dtype == ISG_F32)
         hipLaunchKernelGGL((lstm_pointwise_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, s, p);

@@ -37,3 +37,17 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.isg_raster_iou(None, None, None, None, 4, 16, 28, None, None, None, None, None) == -1
     assert b"null" in lib.isg_last_error()
     assert lib.isg_shape_mask(None, None, 1, 16, 4096, None, None, None) == -1
+
+
+def test_upload_accepts_every_integer_and_float_dtype():
+    """ops.upload on the CPU device (the pinned path needs a GPU): values and requested dtype survive, including
+    the unsigned types torch has no name for."""
+    import numpy as np
+    import torch
+    from imagesegmentation_amd import ops
+    for np_dtype in (np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.float32, np.float64, np.bool_):
+        a = (np.arange(12).reshape(3, 4) % 5).astype(np_dtype)
+        t = ops.upload(a, "cpu", torch.int32)
+        assert t.dtype == torch.int32 and np.array_equal(t.numpy(), a.astype(np.int32))
+    assert ops.upload(np.zeros([0], np.int32), "cpu").numel() == 0
+    assert ops.upload([[1, 2], [3, 4]], "cpu").tolist() == [[1, 2], [3, 4]]

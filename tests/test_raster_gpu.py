@@ -249,3 +249,31 @@ def test_empty_batch_is_a_no_op():
     z1 = torch.zeros([0], dtype=torch.int32, device=dev)
     inter, union = util.raster_iou(z3, z1, z3, z1, 28)
     assert inter.numel() == 0 and union.numel() == 0
+
+
+@pytest.mark.parametrize("end_token", [False, True])
+def test_device_masked_rewards_equal_host_selected_ones(end_token):
+    """step(host_sync=False) rasterises every environment and masks on the device; same rewards and flags as the
+    variant that asks the host which environments finished."""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    P, N = 28, 48
+    ds = data.PolygonDataset.synthetic(16, P, P, 10, 2, seed=9, shape_mask_fn=oracle_raster.create_shape_mask)
+    rs = np.random.RandomState(3)
+    idx = rs.randint(0, len(ds), [N])
+    images, polys = ds._images[idx], [ds._vertices[i] for i in idx]
+    envs = [BatchedPolygonEnv(ds, N, end_token=end_token, max_steps=6, device=_dev()) for _ in range(2)]
+    for e in envs:
+        e.reset(images, polys)
+    saw_terminal = False
+    for t in range(6):
+        a = rs.randint(0, P, [N, 2]).astype(np.int32)
+        close_now = rs.rand(N) < 0.3  # a third of the environments try to finish each step
+        for b in range(N):
+            if close_now[b]:
+                a[b] = (P, 0) if end_token else polys[b][0]
+        outs = [e.step(torch.tensor(a, device=_dev()), host_sync=sync) for e, sync in zip(envs, (True, False))]
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0])
+        saw_terminal |= bool((outs[0][1] > 0).any())
+    assert saw_terminal
