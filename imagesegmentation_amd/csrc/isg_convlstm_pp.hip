@@ -566,12 +566,13 @@ __global__ __launch_bounds__(kPPThreads) void conv_wgrad_pp_kernel(WgradParams p
         }
         info[j] = has ? (ldso | (hy << 20) | (hx << 24)) : -1;
     }
-    // Element offset of pass j's chunk from the tile's first pixel, rebuilt from info at every use (one
-    // register per pass would push the accumulators into scratch): pixel offset * channels + the
-    // chunk's channel offset, which is its byte position in the 64-byte LDS pixel row.
+    // Element offset of pass j's chunk from the tile's first pixel: pixel offset * channels + the chunk's
+    // channel offset, which is its byte position in the 64-byte LDS pixel row.  The two-row-tile kernel rebuilds
+    // it from info at every use (one more register per pass would push its accumulators into scratch); the
+    // one-row-tile kernel has the registers and lets the compiler keep it (6 % of a launch).
     auto rel_of = [&](int j) -> int {
         int inf = info[j];
-        asm volatile("" : "+v"(inf));  // not loop-invariant as far as the compiler can tell: no hoisting
+        if constexpr (MT == 2) asm volatile("" : "+v"(inf));  // not loop-invariant as far as the compiler can tell
         const int hy = (inf >> 20) & 15, hx = (inf >> 24) & 63;
         const int pix = (hy - 1) * p.W + (hx - 1);
         const int chb = inf & 63;
