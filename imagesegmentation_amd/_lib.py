@@ -46,6 +46,9 @@ SIGNATURES = {
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                      _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
+    "isg_convlstm_pooled_fwd_supported": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
+    "isg_convlstm_cell_fwd_pooled": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
+                                            _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _vp, _ll, _vp]),
     "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                           _vp, _int, _vp, _vp, _vp]),
     "isg_convlstm_dgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _int, _int, _vp,

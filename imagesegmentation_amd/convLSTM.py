@@ -286,8 +286,10 @@ class SequenceInput:
         return self._buf
 
 
-def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
-    """Shared by the autograd function and the no-grad decode path."""
+def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, pool=1):
+    """Shared by the autograd function and the no-grad decode path.  ``pool`` = k > 1: the returned outputs
+    are the k x k window means, [B, T, H/k, W/k, F] - written by the top layer's kernel itself where it can,
+    by a pooling pass over the full-resolution outputs otherwise."""
     L, T = len(cells), seq.T
     dt = cells[0].compute_dtype
     B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
@@ -304,7 +306,9 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
         Cs[l][0].zero_() if c0 is None else Cs[l][0].copy_(c0)
         Hs[l][0].zero_() if h0 is None else Hs[l][0].copy_(h0)
     # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
-    out = torch.empty([B, T, H, W, F], dtype=dt, device=dev)
+    fused_pool = pool > 1 and ops.pooled_fwd_supported(packed[L - 1], B, H, W, pool)
+    oh, ow = (H // pool, W // pool) if fused_pool else (H, W)
+    out = torch.empty([B, T, oh, ow, F], dtype=dt, device=dev)
     if t_run < T:
         out[:, t_run:].zero_()
     cur = 0
@@ -313,12 +317,17 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save):
         nxt = cur + 1 if save else 1 - cur
         for l in range(L):
             ops.set_layer(l)
+            top = l == L - 1
             ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
-                         out=out[:, t] if l == L - 1 else None, out_batch_stride=T * H * W * F,
+                         out=out[:, t] if top and not fused_pool else None, out_batch_stride=T * H * W * F,
                          save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
-                         hist_points=seq.points(t) if l == 0 else None)
+                         hist_points=seq.points(t) if l == 0 else None,
+                         pool_out=out[:, t] if top and fused_pool else None, pool_batch_stride=T * oh * ow * F,
+                         pool=pool)
             x = Hs[l][nxt]
         cur = nxt
+    if pool > 1 and not fused_pool:
+        out = ops.avgpool(out, pool)
     final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
     return out, final, (Hs, Cs, Gs, packed)
 
@@ -384,13 +393,12 @@ class _SequenceFunction(torch.autograd.Function):
         cells = list(multi.cells)
         L = len(cells)
         init_state = [(tensors[1 + 2 * l], tensors[2 + 2 * l]) for l in range(L)]
-        out, final, (Hs, Cs, Gs, packed) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, True)
+        out, final, (Hs, Cs, Gs, packed) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, True,
+                                                                 pool)
         ctx.multi, ctx.seq, ctx.durations_dev, ctx.t_run = multi, seq, durations_dev, t_run
         ctx.saved = (Hs, Cs, Gs, packed)
         ctx.in_dtype = tensors[0].dtype
         ctx.pool = pool
-        if pool > 1:  # the caller only wants the k x k window means of the emitted outputs
-            out = ops.avgpool(out, pool)
         ctx.state_dtypes = [(None if c is None else c.dtype, None if h is None else h.dtype) for c, h in init_state]
         # unused outputs (normally the final state) arrive as None in backward instead of zero tensors
         ctx.set_materialize_grads(False)

@@ -692,11 +692,18 @@ extern "C" int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int
     return rc;
 }
 
-extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
-                                     const float* bias, int B, int H, int W, int Cs, int F, int dtype,
-                                     const int32_t* durations, int t, const int32_t* hist_points, int hist,
-                                     long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
-                                     void* out, long long out_batch_stride, void* gates, void* stream) {
+namespace {
+// the fused 8 x 8 pooled output exists in the bf16 ping-pong kernels only, on grids they tile exactly
+bool pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist) {
+    return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32) && pool == 8 && H % TH == 0 && W % TW == 0 &&
+           hist >= 0 && hist <= 2 && (long long)B * H * W * Cs * 2 < (1LL << 32);
+}
+
+int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd, const float* bias,
+                  int B, int H, int W, int Cs, int F, int dtype, const int32_t* durations, int t,
+                  const int32_t* hist_points, int hist, long long hist_batch_stride, const float* hist_table,
+                  void* h_out, float* c_out, void* out, long long out_batch_stride, void* gates, void* pool_out,
+                  long long pool_batch_stride, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(x && h_prev && c_prev && packed_fwd && bias && h_out && c_out, ISG_EINVAL,
                 "isg_convlstm_cell_fwd: null pointer");
@@ -714,6 +721,7 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const fl
     p.durations = durations, p.t = t;
     p.bias = bias, p.c_prev = c_prev, p.c_out = c_out, p.h_out = h_out, p.out = out;
     p.out_bstride = out_batch_stride, p.gates = gates;
+    p.pool_out = pool_out, p.pool_bstride = pool_batch_stride;
     p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_table = hist_table;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32) {
@@ -723,7 +731,38 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const fl
     p.spt = (Cs + F_) / 16;
     rc = launch_conv_pp(p, 2, 0, num_cus(), s);
     if (rc != kNotSupported) return rc;
+    ISG_REQUIRE(pool_out == nullptr, ISG_EINVAL, "isg_convlstm_cell_fwd_pooled: no kernel with a pooled output for this shape");
     return launch_conv<__bf16, 2, 0>(p, s);
+}
+}  // namespace
+
+extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+                                     const float* bias, int B, int H, int W, int Cs, int F, int dtype,
+                                     const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                                     long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
+                                     void* out, long long out_batch_stride, void* gates, void* stream) {
+    return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
+                         hist_batch_stride, hist_table, h_out, c_out, out, out_batch_stride, gates, nullptr, 0, stream);
+}
+
+extern "C" int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist) {
+    return pooled_fwd_supported(Cs, F, dtype, B, H, W, pool, hist) ? 1 : 0;
+}
+
+extern "C" int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const float* c_prev,
+                                            const void* packed_fwd, const float* bias, int B, int H, int W, int Cs,
+                                            int F, int dtype, const int32_t* durations, int t,
+                                            const int32_t* hist_points, int hist, long long hist_batch_stride,
+                                            const float* hist_table, void* h_out, float* c_out, void* gates,
+                                            int pool, void* pool_out, long long pool_batch_stride, void* stream) {
+    ISG_REQUIRE(pool_out, ISG_EINVAL, "isg_convlstm_cell_fwd_pooled: null pooled output");
+    ISG_REQUIRE(pooled_fwd_supported(Cs, F, dtype, B, H, W, pool, hist), ISG_EINVAL,
+                "isg_convlstm_cell_fwd_pooled: needs bf16, Cs 16 or 32, pool 8, H %% 8 == 0 and W %% 32 == 0 "
+                "(got Cs=%d dtype=%d pool=%d %dx%d): ask isg_convlstm_pooled_fwd_supported first",
+                Cs, dtype, pool, H, W);
+    return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
+                         hist_batch_stride, hist_table, h_out, c_out, nullptr, 0, gates, pool_out, pool_batch_stride,
+                         stream);
 }
 
 extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur,

@@ -72,7 +72,8 @@ struct PP {
     static constexpr int NL1 = (NPX_ * NCH1 + 255) / 256;
     static constexpr int NLOAD = NL0 + NL1;
     static constexpr int TAB_FLOATS = NG + 9 * 2 * NG;     // bias + history taps (hist <= 2)
-    static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + (MODE == 0 ? TAB_FLOATS * 4 : 0);
+    static constexpr int POOL_FLOATS = 2 * 4 * 4 * F_;     // per group and wave: 4 windows x F partial sums
+    static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + (MODE == 0 ? (TAB_FLOATS + POOL_FLOATS) * 4 : 0);
 };
 
 // EARLY: request the tile after next already in the finish phase (two phases of flight, ahead of the
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     char* lds_w = smem;
     char* lds_in = smem + K::W_BYTES + grp * K::IN_BYTES;
     float* lds_tab = reinterpret_cast<float*>(smem + K::W_BYTES + 2 * K::IN_BYTES);
+    float* lds_pool = lds_tab + K::TAB_FLOATS;
 
     {  // weight image and tables, once per workgroup
         const uint4* src = static_cast<const uint4*>(p.wimg);
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 near_point |= hpx[i] >= 0 && hpy[i] >= wy0 - 1 && hpy[i] <= wy0 + NPT && hpx[i] >= r.tx0 - 1 &&
                               hpx[i] <= r.tx0 + TW;
         }
+        float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's channels summed over its rows
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int gy = r.ty0 + NPT * wave + pt, gx = r.tx0 + px_l;
@@ -344,6 +347,10 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 store8(static_cast<T*>(p.h_out) + so, hn);
                 if (p.out)
                     store8(static_cast<T*>(p.out) + (size_t)r.b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
+                if (p.pool_out) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) psum[c] += (float)(T)hn[c];  // the pool averages the STORED values
+                }
             } else {
                 const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
 #pragma unroll
@@ -363,6 +370,50 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                         }
                     }
             }
+        }
+        if constexpr (MODE == 0) {
+            if (p.pool_out) {
+                // 8 x 8 window = 8 columns (lanes) x this wave's 2 rows x the group's 4 waves: columns through
+                // DPP, the waves through LDS, combined by the group at the start of its next phase
+                auto dpp_add = [](float v, auto ctrl) {
+                    return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v),
+                                                                                   decltype(ctrl)::value, 0xf, 0xf, true));
+                };
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v = psum[c];
+                    v = dpp_add(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+                    v = dpp_add(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+                    v = dpp_add(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: the other four lanes
+                    psum[c] = v;
+                }
+                if ((px_l & 7) == 0) {
+                    float* dst = lds_pool + ((grp * 4 + wave) * 4 + (px_l >> 3)) * F_ + 8 * half;
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{psum[0], psum[1], psum[2], psum[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{psum[4], psum[5], psum[6], psum[7]};
+                }
+            }
+        }
+    };
+
+    // The pooled means of the tile whose epilogue ran in this group's last finish phase (the barrier in between
+    // made every wave's partial sums visible): 4 windows x 16 channels = one 128-byte run.
+    bool pool_pending = false;
+    auto pool_flush = [&](const TileRef& r) {
+        if constexpr (MODE == 0) {
+            if (!pool_pending) return;
+            pool_pending = false;
+            if (wave != 0) return;
+            const int win = lane >> 4, ch = lane & 15;
+            float v = 0.0f;
+            if (r.live) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += lds_pool[((grp * 4 + w) * 4 + win) * F_ + ch];
+                v *= 1.0f / 64.0f;
+            }
+            T* dst = static_cast<T*>(p.pool_out) + (size_t)r.b * p.pool_bstride +
+                     ((size_t)(r.ty0 >> 3) * (p.W >> 3) + (r.tx0 >> 3) + win) * F_ + ch;
+            *dst = (T)v;
         }
     };
 
@@ -394,6 +445,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     for (int h = 0; h < n_half; ++h) {
         STAMP(t0);
         if (((h + grp) & 1) == 0) {
+            pool_flush(done);
             // The partner wave on this SIMD is in its finish phase, a long run of vector ALU work (gate math) that
             // would otherwise win most issue slots: the few instructions that put this phase's loads in flight go
             // first (measured: 3 - 10 % of a launch).
@@ -424,6 +476,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             }
             STAMP(t1);
             if (have_acc) epilogue(done);
+            if constexpr (MODE == 0) pool_pending = have_acc && done.valid && p.pool_out != nullptr;
             have_acc = false;
             STAMP(t2);
             STAMP_ADD(2, t0, t1);  // wait for the staged loads + LDS writes

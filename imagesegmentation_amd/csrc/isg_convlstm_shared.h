@@ -91,6 +91,10 @@ struct ConvParams {
     void* out;             // masked output or null; sample stride out_bstride elements
     long long out_bstride;
     void* gates;           // [B,H,W,F,4] (g,i,f,o) or null
+    // pooled output of the ping-pong kernels: means of the masked output over 8 x 8 windows,
+    // [H/8][W/8][F] per sample with sample stride pool_bstride elements; null = none
+    void* pool_out;
+    long long pool_bstride;
     // dgrad epilogue
     void* dx;              // [B,H,W,dx_cstride] or null
     int dx_channels, dx_cstride, dx_accumulate;

@@ -146,11 +146,22 @@ def _points_arg(hist_points, hist):
     return hist_points.data_ptr(), hist_points.stride(0)
 
 
+def pooled_fwd_supported(packed, B, H, W, pool):
+    """Whether cell_fwd can deliver its emitted output already averaged over pool x pool windows
+    (ISG_NO_FUSED_POOL=1 answers no: the separate pooling pass, for A/B runs)."""
+    if os.environ.get("ISG_NO_FUSED_POOL"):
+        return False
+    return bool(_lib.lib().isg_convlstm_pooled_fwd_supported(packed.cs, packed.f, dtype_code(packed.dtype), int(B),
+                                                             int(H), int(W), int(pool), packed.hist))
+
+
 @_timed("cell_fwd")
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
-             h_out=None, c_out=None, gates=None, hist_points=None):
+             h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
     hist_points: int32 [B,hist,2] when the packed weights carry history channels.
+    ``pool_out`` ([B, H/pool, W/pool, F] view with batch stride ``pool_batch_stride``; only where
+    ``pooled_fwd_supported``) receives the window means of the emitted output instead of ``out``.
     Returns (h, c, gates)."""
     _need_cuda(x, "x")
     B, H, W, Cs = x.shape
@@ -162,6 +173,15 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     if gates is None and save_gates:
         gates = torch.empty([B, H, W, F, 4], dtype=x.dtype, device=x.device)
     pts, pts_stride = _points_arg(hist_points, packed.hist)
+    if pool_out is not None:
+        assert out is None and pool_out.dtype == x.dtype
+        rc = _lib.lib().isg_convlstm_cell_fwd_pooled(
+            _lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd), _lib.ptr(packed.bias), B, H, W, Cs,
+            F, dtype_code(x.dtype), _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,
+            _lib.ptr(packed.hist_table), _lib.ptr(h), _lib.ptr(c), _lib.ptr(gates), int(pool), pool_out.data_ptr(),
+            int(pool_batch_stride), _lib.current_stream())
+        _lib.check(rc, "isg_convlstm_cell_fwd_pooled")
+        return h, c, gates
     rc = _lib.lib().isg_convlstm_cell_fwd(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd),
                                           _lib.ptr(packed.bias), B, H, W, Cs, F, dtype_code(x.dtype),
                                           _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,

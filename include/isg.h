@@ -139,6 +139,19 @@ int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev
                           long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out, void* out,
                           long long out_batch_stride, void* gates, void* stream);
 
+/* The same step for a caller that only wants the emitted output AVERAGED over pool x pool windows (the head on
+ * a coarser grid, see isg_avgpool_fwd): pool_out `dtype` [H/pool][W/pool][F] per sample, samples
+ * pool_batch_stride elements apart, zeros for a masked sample; the full-resolution output is never written.
+ * No counterpart in the reference (its head reads the full grid, polyrnn/History2LargeExperiment.py:48-50).
+ * Only where isg_convlstm_pooled_fwd_supported(...) returns 1 (bf16, Cs 16 or 32, pool 8, H % 8 == 0,
+ * W % 32 == 0); otherwise use isg_convlstm_cell_fwd + isg_avgpool_fwd. */
+int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist);
+int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+                                 const float* bias, int B, int H, int W, int Cs, int F, int dtype,
+                                 const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                                 long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
+                                 void* gates, int pool, void* pool_out, long long pool_batch_stride, void* stream);
+
 /* Backward, step 1 (pointwise): from dL/dh (= dh_above as emitted output + dh_state as carried
  * state, either may be NULL) and dL/dc (dc_state, may be NULL) to the pre-activation gradient
  * dy [B][H][W][F][4] and dc_prev (may alias dc_state).  Replaces the gradient of

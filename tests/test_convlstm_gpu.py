@@ -375,3 +375,50 @@ def test_pointwise_backward_carry_dtype(dtype):
     assert torch.equal(dy32, dy16)
     assert torch.equal(dcp32.bfloat16(), dcp16)
     assert torch.equal(dcp16[1], dc[1])  # a finished sample passes its carry through
+
+
+@pytest.mark.parametrize("C,hist", [(16, 0), (31, 1), (16, 2)])
+def test_pooled_output_from_the_cell_kernel(C, hist):
+    """cell_fwd writing 8 x 8 window means itself against cell_fwd + the pooling kernel: identical state,
+    pooled values equal to bf16 rounding (float sums of the same bf16 outputs in another order), zeros for a
+    finished sample; then the whole sequence node with output_pool=8 against pooling its unpooled outputs."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
+    rs = np.random.RandomState(31)
+    dt = torch.bfloat16
+    B, H, W, F = 3, 16, 64, 16
+    w_x, w_h, bias = rand_cell(rs, C + hist)
+    cell = make_cell(C + hist, w_x, w_h, bias, dt, (H, W))
+    packed = cell.packed(hist=hist)
+    assert ops.pooled_fwd_supported(packed, B, H, W, 8) and not ops.pooled_fwd_supported(packed, B, H, 56, 8)
+    t32 = lambda a: torch.tensor(a, dtype=torch.float32, device=dev())
+    x = t32(rs.randn(B, H, W, packed.cs)).to(dt)
+    x[..., C:] = 0
+    h, c = t32(rs.randn(B, H, W, F) * 0.5).to(dt), t32(rs.randn(B, H, W, F))
+    pts = torch.tensor(rs.randint(0, 16, [B, hist, 2]), dtype=torch.int32, device=dev()) if hist else None
+    dur = torch.tensor([3, 1, 2], dtype=torch.int32, device=dev())
+    out = torch.empty([B, H, W, F], dtype=dt, device=dev())
+    h1, c1, _ = ops.cell_fwd(x, h, c, packed, dur, 1, out=out, out_batch_stride=H * W * F, save_gates=False,
+                             hist_points=pts)
+    pooled = torch.full([B, H // 8, W // 8, F], 7.0, dtype=dt, device=dev())
+    h2, c2, _ = ops.cell_fwd(x, h, c, packed, dur, 1, save_gates=False, hist_points=pts, pool_out=pooled,
+                             pool_batch_stride=(H // 8) * (W // 8) * F, pool=8)
+    assert torch.equal(h1, h2) and torch.equal(c1, c2)
+    want = ops.avgpool(out, 8).float()
+    assert float(pooled[1].abs().max()) == 0.0 and float(want[1].abs().max()) == 0.0
+    assert float((pooled.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
+    # the sequence node: pooled inside the kernel vs. pooled afterwards
+    T = 3
+    feats = t32(rs.randn(B, H, W, C)).to(dt)
+    spts = torch.tensor(rs.randint(0, 16, [B, T, hist, 2]), dtype=torch.int32, device=dev())
+    cell2 = make_cell(16, *rand_cell(rs, 16), dt, (H, W))
+    from imagesegmentation_amd.convLSTM import MultiRNNCell
+    multi = MultiRNNCell([cell, cell2])
+    seq = SequenceInput(static=feats, hist_points=spts)
+    durations = np.array([3, 0, 2], np.int32)
+    full, _ = dynamic_rnn(multi, seq, sequence_length=durations, time_major=False)
+    pooled_seq, _ = dynamic_rnn(multi, seq, sequence_length=durations, time_major=False, output_pool=8)
+    want = ops.avgpool(full.contiguous(), 8).float()
+    assert tuple(pooled_seq.shape) == (B, T, H // 8, W // 8, F)
+    assert float((pooled_seq.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
+    assert float(pooled_seq[1].abs().max()) == 0.0 and float(pooled_seq[2, 2:].abs().max()) == 0.0
