@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libisg.so")
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
 _f32 = ctypes.c_float
+_f64 = ctypes.c_double
 _ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/isg.h one to one
@@ -46,6 +47,7 @@ SIGNATURES = {
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                      _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
+    "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),
     "isg_convlstm_pooled_fwd_supported": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
     "isg_convlstm_cell_fwd_pooled": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                             _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _vp, _ll, _vp]),

@@ -101,7 +101,7 @@ class ConvLSTMCell(torch.nn.Module):
         """Operand images of the current weights; rebuilt whenever a parameter changed in place.
         ``hist`` trailing input channels are one-hot history frames handled as a tap scatter."""
         params = (self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias)
-        key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype, hist)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype, hist, ops.weights_epoch())
         if self._packed is None or self._packed_key != key:
             cs = ops.padded_channels(self.input_to_state_kernel.shape[2] - hist, self.compute_dtype)
             self._packed = ops.PackedWeights(self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias, cs,

@@ -35,6 +35,29 @@ def upload(array, device, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+_weights_epoch = 0
+
+
+def weights_epoch():
+    """Counts optimiser steps taken by ``adam_tf_``: the kernel updates parameters behind torch's back (no
+    version counter moves), so anything cached from parameter values keys on this as well."""
+    return _weights_epoch
+
+
+def adam_tf_(param, m, v, grad, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_norm=None, clip_norm=None):
+    """One TensorFlow-form Adam step over flat float32 buffers in one launch (isg_adam_tf); with ``clip_norm``
+    the gradient is scaled by clip_norm / max(grad_norm, clip_norm) on the fly (grad_norm: device scalar)."""
+    global _weights_epoch
+    for t in (param, m, v, grad):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    _need_cuda(param, "param")
+    rc = _lib.lib().isg_adam_tf(_lib.ptr(param), _lib.ptr(m), _lib.ptr(v), _lib.ptr(grad), param.numel(), float(lr_t),
+                                float(beta1), float(beta2), float(eps), _lib.ptr(grad_norm),
+                                float(clip_norm) if clip_norm is not None else 0.0, _lib.current_stream())
+    _lib.check(rc, "isg_adam_tf")
+    _weights_epoch += 1
+
+
 def dtype_code(dtype):
     if dtype == torch.float32:
         return 0

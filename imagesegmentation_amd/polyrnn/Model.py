@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, util
+from ..optim import adam_tf_step_, flatten_parameters_
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, MultiRNNCell, RecurrentStepper, SequenceInput, dynamic_rnn
 from . import decode
 
@@ -188,9 +189,12 @@ class Model:
         self._build_graph()
         self._make_variables()
         self.trainable_variables = [p for _, p in self._named_parameters()]
-        self._adam_m = [torch.zeros_like(p) for p in self.trainable_variables]
-        self._adam_v = [torch.zeros_like(p) for p in self.trainable_variables]
-        n = sum(p.numel() for p in self.trainable_variables)
+        # parameters, gradients and both Adam moments each live in one flat buffer: one all-reduce, one norm,
+        # one update launch
+        self._flat_param = flatten_parameters_(self.trainable_variables)
+        self._adam_m = torch.zeros_like(self._flat_param)
+        self._adam_v = torch.zeros_like(self._flat_param)
+        n = self._flat_param.numel()
         self._flat_grad = torch.zeros([n], dtype=torch.float32, device=self.device)
         off = 0
         head_at = None
@@ -293,7 +297,7 @@ class Model:
         w, b = self.dense_kernel, self.dense_bias
         if flat.dtype != w.dtype and not torch.is_grad_enabled():
             # decode loops call the head once per step with unchanged weights: convert them once
-            key = (flat.dtype, w._version, b._version, w.data_ptr())
+            key = (flat.dtype, w._version, b._version, w.data_ptr(), ops.weights_epoch())
             if getattr(self, "_head_cast_key", None) != key:
                 self._head_cast = (w.detach().to(flat.dtype), b.detach().to(flat.dtype))
                 self._head_cast_key = key
@@ -338,21 +342,10 @@ class Model:
         if all_reduce:
             self._early_reduce.finish(average=average)
         norm = flat.norm()
-        if clip:  # tf.clip_by_global_norm(grads, 1.0): scale = clip / max(norm, clip)
-            flat.mul_(1.0 / torch.clamp(norm, min=1.0))
         self.global_step += 1
-        t = self.global_step
-        b1, b2, eps = 0.9, 0.999, 1e-8
-        lr_t = self.learning_rate * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-        grads = [p.grad for p in self.trainable_variables]
-        with torch.no_grad():
-            torch._foreach_mul_(self._adam_m, b1)
-            torch._foreach_add_(self._adam_m, grads, alpha=1 - b1)
-            torch._foreach_mul_(self._adam_v, b2)
-            torch._foreach_addcmul_(self._adam_v, grads, grads, value=1 - b2)
-            denom = torch._foreach_sqrt(self._adam_v)
-            torch._foreach_add_(denom, eps)
-            torch._foreach_addcdiv_(self.trainable_variables, self._adam_m, denom, value=-lr_t)
+        # tf.clip_by_global_norm(grads, 1.0) (scale = clip / max(norm, clip)) is applied inside the update
+        adam_tf_step_(self._flat_param, self._adam_m, self._adam_v, flat, self.global_step, self.learning_rate,
+                      clip_norm=1.0 if clip else None, norm=norm)
         return norm
 
     def train_step(self, images, durations, histories, targets):

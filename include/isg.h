@@ -233,6 +233,17 @@ int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsign
 int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T, int P,
                          double* out4, void* stream);
 
+/* ---- optimiser ----------------------------------------------------------------------------------
+ * tf.clip_by_global_norm + tf.train.AdamOptimizer as the reference applies them (polyrnn/Model.py:106-112;
+ * polyrl/a3c/a3c.py:244-258 with clip 40) over flat float buffers of n values, one pass:
+ *   g = grad * (clip_norm / max(*grad_norm, clip_norm))      (grad_norm: device float, the global norm of grad;
+ *                                                             NULL or clip_norm <= 0: no clipping)
+ *   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;  param -= lr_t m / (sqrt(v) + eps)
+ * lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) is the caller's (TensorFlow's form: eps is not rescaled).
+ * grad is not modified.  All four buffers 16-byte aligned. */
+int isg_adam_tf(float* param, float* m, float* v, const float* grad, long long n, double lr_t, double beta1,
+                double beta2, double eps, const float* grad_norm, double clip_norm, void* stream);
+
 /* ---- head pooling ----------------------------------------------------------------------------
  * Mean over non-overlapping k x k windows of x [N][H][W][F] -> out [N][H/k][W/k][F], same dtype,
  * float accumulation.  The reference feeds the recurrent output straight into

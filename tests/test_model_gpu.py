@@ -337,3 +337,32 @@ def test_fp32_model_against_committed_golden_outputs(name):
         assert abs(mine[1] - s[1]) < 2e-4 * scale, (name, tuple(g.shape))
         # sum and random projection are sums of n terms of size ~norm/sqrt(n): compare on the norm's scale
         assert abs(mine[0] - s[0]) < 2e-4 * scale * np.sqrt(g.numel()) and abs(mine[2] - s[2]) < 2e-3 * scale
+
+
+def test_fused_adam_matches_the_tensorflow_form():
+    """isg_adam_tf over a flat buffer whose length is not a multiple of 4, three steps with the global-norm clip
+    active and inactive, against the update written out with torch ops in float64."""
+    from imagesegmentation_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    n = 4 * 1000 + 3
+    p = torch.randn([n], device=dev, generator=g)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    rp, rm, rv = p.double(), m.double(), v.double()
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+    epoch = ops.weights_epoch()
+    for t, (gscale, clip) in enumerate([(5.0, 1.0), (1e-3, 1.0), (2.0, None)], start=1):
+        grad = torch.randn([n], device=dev, generator=g) * gscale
+        kept = grad.clone()
+        norm = grad.norm()
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ops.adam_tf_(p, m, v, grad, lr_t, b1, b2, eps, grad_norm=norm if clip else None, clip_norm=clip)
+        assert torch.equal(grad, kept)  # the gradient itself is left alone
+        gd = grad.double() * (clip / max(float(norm), clip) if clip else 1.0)
+        rm = b1 * rm + (1 - b1) * gd
+        rv = b2 * rv + (1 - b2) * gd * gd
+        rp = rp - lr_t * rm / (rv.sqrt() + eps)
+        assert float((p.double() - rp).abs().max()) <= 1e-6 * float(rp.abs().max())
+        assert float((m.double() - rm).abs().max()) <= 1e-6 * float(rm.abs().max()) + 1e-12
+        assert float((v.double() - rv).abs().max()) <= 1e-6 * float(rv.abs().max()) + 1e-12
+    assert ops.weights_epoch() == epoch + 3
