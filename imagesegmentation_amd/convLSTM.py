@@ -286,6 +286,17 @@ class SequenceInput:
         return self._buf
 
 
+_ZERO_STATES = {}
+
+
+def _zero_state(shape, dtype, device):
+    key = (tuple(shape), dtype, str(device))
+    z = _ZERO_STATES.get(key)
+    if z is None:
+        z = _ZERO_STATES[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return z
+
+
 def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, pool=1):
     """Shared by the autograd function and the no-grad decode path.  ``pool`` = k > 1: the returned outputs
     are the k x k window means, [B, T, H/k, W/k, F] - written by the top layer's kernel itself where it can,
@@ -296,15 +307,18 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     dev = seq.device
     packed = [seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
     seq.prepare(dt, packed[0].cs)
-    n_keep = T + 1 if save else 2
-    Hs = [torch.empty([n_keep, B, H, W, F], dtype=dt, device=dev) for _ in range(L)]
-    Cs = [torch.empty([n_keep, B, H, W, F], dtype=torch.float32, device=dev) for _ in range(L)]
-    Gs = [torch.empty([T, B, H, W, F, 4], dtype=dt, device=dev) for _ in range(L)] if save else None
+    # Per layer a list of state tensors: entry 0 is the initial state, entry k the state after step k - 1 when
+    # everything is kept for backward, else entries 1 and 2 alternate.  None = zero state: ONE zero tensor per
+    # shape, kept for the life of the process and only ever read - neither a fill nor a copy per sequence.
+    n_buf = T if save else 2
+    Hs, Cs = [], []
     for l in range(L):
         c0, h0 = init_state[l]
-        # None = zero state: a fill, not a copy of a zero tensor
-        Cs[l][0].zero_() if c0 is None else Cs[l][0].copy_(c0)
-        Hs[l][0].zero_() if h0 is None else Hs[l][0].copy_(h0)
+        c_init = _zero_state([B, H, W, F], torch.float32, dev) if c0 is None else c0.detach().to(torch.float32).contiguous()
+        h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
+        Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
+        Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=torch.float32, device=dev).unbind(0)))
+    Gs = [torch.empty([T, B, H, W, F, 4], dtype=dt, device=dev) for _ in range(L)] if save else None
     # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
     fused_pool = pool > 1 and ops.pooled_fwd_supported(packed[L - 1], B, H, W, pool)
     oh, ow = (H // pool, W // pool) if fused_pool else (H, W)
@@ -314,7 +328,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     cur = 0
     for t in range(t_run):
         x = seq.get(t)
-        nxt = cur + 1 if save else 1 - cur
+        nxt = cur + 1 if save else (2 if cur == 1 else 1)
         for l in range(L):
             ops.set_layer(l)
             top = l == L - 1
@@ -328,7 +342,10 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         cur = nxt
     if pool > 1 and not fused_pool:
         out = ops.avgpool(out, pool)
-    final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
+    if cur == 0:  # no step ran: hand out copies, never the shared zero tensors or the caller's own state
+        final = [(Cs[l][0].clone(), Hs[l][0].clone()) for l in range(L)]
+    else:
+        final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
     return out, final, (Hs, Cs, Gs, packed)
 
 
@@ -415,7 +432,7 @@ class _SequenceFunction(torch.autograd.Function):
         Hs, Cs, Gs, packed = ctx.saved
         dt = cells[0].compute_dtype
         B, H, W, F, T = seq.B, seq.H, seq.W, cells[0]._filters, seq.T
-        dev = Hs[0].device
+        dev = Hs[0][0].device
         pool = ctx.pool
         d_out = d_out.to(dt).contiguous() if d_out is not None else \
             torch.zeros([B, T, H // pool, W // pool, F], dtype=dt, device=dev)
