@@ -560,6 +560,7 @@ __global__ void hist_table_kernel(const float* __restrict__ w_x, int C, int hist
 
 // dw_x[tap][C + i][:] (+)= sum over live samples of dY at the one pixel that tap reaches from the point
 constexpr int kHistGroups = 16;  // sample groups per workgroup
+constexpr int kHistChunk = 2048;  // samples located per pass
 template <typename T>
 __global__ __launch_bounds__(kHistGroups * NG) void hist_wgrad_kernel(const T* __restrict__ dy,
                                                                      const int* __restrict__ pts, long long pts_bstride,
@@ -567,22 +568,32 @@ __global__ __launch_bounds__(kHistGroups * NG) void hist_wgrad_kernel(const T* _
                                                                      const int* __restrict__ durations, int t,
                                                                      int accumulate, float* __restrict__ dw_x) {
     __shared__ float red[kHistGroups][NG];
+    __shared__ long long where[kHistChunk];  // element offset of the one pixel a sample contributes, or -1
     const int tap = blockIdx.x / hist, i = blockIdx.x - tap * hist;
     const int k = threadIdx.x & (NG - 1);  // dY channel, (channel, gate) order
     const int sg = threadIdx.x / NG;       // the samples are dealt to kHistGroups groups of threads
     const int ty = tap / 3, tx = tap - ty * 3;
     float sum = 0.0f;
-    // every load of a sample is unconditional (a masked sample reads element 0 and adds nothing), so the
-    // unrolled loop keeps four samples' dependent chains (length, point, dY) in flight at once
-#pragma unroll 4
-    for (int b = sg; b < B; b += kHistGroups) {
-        const bool live = durations == nullptr || t < durations[b];
-        const int px = pts[(size_t)b * pts_bstride + 2 * i], py = pts[(size_t)b * pts_bstride + 2 * i + 1];
-        const int gy = py - ty + 1, gx = px - tx + 1;
-        const bool hit = live && px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t at = hit ? (((size_t)b * H + gy) * W + gx) * NG + k : (size_t)k;
-        const float v = (float)dy[at];
-        sum += hit ? v : 0.0f;
+    for (int b0 = 0; b0 < B; b0 += kHistChunk) {
+        const int nb = min(kHistChunk, B - b0);
+        // first where every sample's pixel is (coalesced reads of lengths and points, one sample per thread) ...
+        __syncthreads();
+        for (int j = threadIdx.x; j < nb; j += kHistGroups * NG) {
+            const int b = b0 + j;
+            const bool live = durations == nullptr || t < durations[b];
+            const int px = pts[(size_t)b * pts_bstride + 2 * i], py = pts[(size_t)b * pts_bstride + 2 * i + 1];
+            const int gy = py - ty + 1, gx = px - tx + 1;
+            const bool hit = live && px >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            where[j] = hit ? (((long long)b * H + gy) * W + gx) * NG : -1;
+        }
+        __syncthreads();
+        // ... then the gather itself: independent loads, eight in flight per thread
+#pragma unroll 8
+        for (int j = sg; j < nb; j += kHistGroups) {
+            const long long at = where[j];
+            const float v = (float)dy[(at >= 0 ? at : 0) + k];
+            sum += at >= 0 ? v : 0.0f;
+        }
     }
     red[sg][k] = sum;
     __syncthreads();
