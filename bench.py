@@ -50,6 +50,8 @@ def parse():
                     help="keep MIOpen's immediate-mode pick for the encoder convs instead of letting it time its solvers "
                          "during warm-up")
     ap.add_argument("--a3c-envs", type=int, default=1024, help="actor-critic environments per GPU (0 = skip)")
+    ap.add_argument("--settle-seconds", type=float, default=8.0,
+                    help="idle pause before the warm-up (see main: the after-effect of a process that just ended)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -381,6 +383,15 @@ def main():
     def step():
         return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
 
+    # A process that starts within a few seconds of the end of another GPU-heavy one on the same device (the
+    # scaling sweep runs N = 1, 2, 4, 8 back to back) was measured launching kernels 10x slower from about half a
+    # second into its steps until about 8 s after the other one ended - host-side issue time 200 ms per step
+    # instead of 2, kernel durations unchanged (tools/exp_steps.py).  Idling through that window keeps it out
+    # of the timed region; it costs nothing the metric counts.
+    if args.settle_seconds > 0:
+        note("settling pause of %.0f s" % args.settle_seconds)
+        torch.cuda.synchronize()
+        time.sleep(args.settle_seconds)
     note("model and batch ready; warm-up (the first step includes the convolution solver search)")
     for _ in range(args.warmup):
         step()

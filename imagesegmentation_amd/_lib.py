@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libisg.so")
+# ISG_LIBRARY points at another build of the same ABI (variant libraries for A/B runs of kernel changes)
+LIB_PATH = os.environ.get("ISG_LIBRARY") or os.path.join(_HERE, "libisg.so")
 
 _vp = ctypes.c_void_p
 _int = ctypes.c_int

@@ -62,7 +62,11 @@ struct PP {
     static constexpr int NCH = CPT / 8;
     static constexpr int SPT = CPT / 16;         // k-steps per tap
     static constexpr int NS = 9 * SPT;
-    static constexpr int PSTRIDE = CPT * 2 + 16;  // LDS bytes per staged pixel (pad spreads banks)
+    // The two-row-tile data gradient on 8-row pixel tiles only fits the 160 KB of LDS without padding: its staged
+    // pixels are 128 bytes apart and the 16-byte chunks of a pixel are stored XOR-ed with the pixel index's low
+    // three bits instead, which spreads eight neighbouring pixels' reads of one chunk over all banks as well.
+    static constexpr bool SWZ = MODE == 1 && MT == 2 && NPT == 2 && C0 == 64 && C1 == 0;
+    static constexpr int PSTRIDE = SWZ ? CPT * 2 : CPT * 2 + 16;  // LDS bytes per staged pixel (pad spreads banks)
     static constexpr int IN_BYTES = (NPX_ * PSTRIDE + 15) & ~15;
     static constexpr int W_BYTES = NS * MT * 1024;
     static constexpr int NCH1 = NCH - NCH0;
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         const int cidx = exists ? idx : K::NPX_ * nch - 1;
         const int px = cidx / nch, chl = cidx - px * nch;
         const int hy = px / HALO_W, hx = px - hy * HALO_W;
-        const unsigned ldso = px * K::PSTRIDE + ((second ? K::NCH0 : 0) + chl) * 16;
+        const int chunk = (second ? K::NCH0 : 0) + chl;
+        const unsigned ldso = px * K::PSTRIDE + (K::SWZ ? chunk ^ (px & 7) : chunk) * 16;
         info[j] = ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
     }
     auto stage_load = [&](const TileRef& r) {
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         const int row0 = r.b * p.H;
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const unsigned inf = info[j];
+            unsigned inf = info[j];
+            // with this many passes the unpacked fields must not be kept in registers of their own across the k-loop
+            if constexpr (K::SWZ) asm volatile("" : "+v"(inf));
             const int hy = (inf >> 16) & 15, hx = (inf >> 20) & 63;
             const int gy = r.ty0 - 1 + hy, gx = r.tx0 - 1 + hx;
             if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) st_inside |= 1u << j;
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         if (!r.live) return;
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
-            const unsigned inf = info[j];
+            unsigned inf = info[j];
+            if constexpr (K::SWZ) asm volatile("" : "+v"(inf));  // as in stage_load
             const bool in = (st_inside >> j) & 1u;
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
             if (inf & 0x80000000u) *reinterpret_cast<uint4*>(lds_in + (inf & 0xFFFFu)) = v;
@@ -212,12 +220,18 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                     for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.0f;
                 }
             }
-        const char* bb = lds_in + ((NPT * wave) * HALO_W + px_l) * K::PSTRIDE + half * 16;
+        const int lane_px = (NPT * wave) * HALO_W + px_l;
+        const char* bb = lds_in + lane_px * K::PSTRIDE + (K::SWZ ? 0 : half * 16);
         const char* aw = lds_w + lane * 16;
+        // swizzled image: chunk 2 q + half of the pixel lane_px + c sits at byte ((2 q + half) ^ ((lane_px + c) & 7)) * 16
+        int lane_px7 = lane_px & 7;
+        const int half_bit = half << 4;
+        if constexpr (K::SWZ) asm volatile("" : "+v"(lane_px7));  // else every fetch address of the k-loop is kept
+                                                                    // in a register of its own across tiles
         bf16x8 a[2][MT], bf[2][NPT];
         auto fetch = [&](int s, int slot) {
             const int tap = s / K::SPT, q = s - tap * K::SPT;
-            const int off = ((tap / 3) * HALO_W + (tap % 3)) * K::PSTRIDE + q * 32;
+            const int off = ((tap / 3) * HALO_W + (tap % 3)) * K::PSTRIDE + (K::SWZ ? 0 : q * 32);
             // the forward image interleaves the row tiles per k-step; the data-gradient image keeps each row
             // tile's k-steps together (a launch may also take a single tile of it)
 #pragma unroll
@@ -225,7 +239,15 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 a[slot][t] = *reinterpret_cast<const bf16x8*>(aw + (MODE == 1 ? t * K::NS + s : s * MT + t) * 1024);
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
-                bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + pt * HALO_W * K::PSTRIDE + off);
+            {
+                if constexpr (K::SWZ) {
+                    const int c7 = (pt * HALO_W + (tap / 3) * HALO_W + (tap % 3)) & 7;
+                    bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + pt * HALO_W * K::PSTRIDE + off +
+                                                                    ((q << 5) ^ half_bit ^ (((lane_px7 + c7) & 7) << 4)));
+                } else {
+                    bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + pt * HALO_W * K::PSTRIDE + off);
+                }
+            }
         };
         fetch(0, 0);
 #pragma unroll
@@ -247,7 +269,8 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     // accumulating) are requested at the START of the compute phase and consumed one phase later, so
     // no load latency is exposed between the MFMAs and the stores.
     constexpr int NPRE = MODE == 0 ? 4 : NPT * MT * 4;
-    uint4 pre[NPRE];
+    using PreT = std::conditional_t<MODE == 0, uint4, uint2>;  // 16 bytes of c_prev / 8 bytes of dx per entry
+    PreT pre[NPRE];
     auto prefetch_epilogue = [&](const TileRef& r) {
         if (!(r.valid && r.live)) return;
 #pragma unroll
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                             uint2 v = make_uint2(0u, 0u);
                             if (cc0 < p.row_split && cc0 < p.dx_channels)
                                 v = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.dx) + pixel * p.dx_cstride + cc0);
-                            pre[(pt * MT + t) * 4 + a4] = make_uint4(v.x, v.y, 0u, 0u);
+                            pre[(pt * MT + t) * 4 + a4] = v;
                         }
                 }
             }
@@ -361,7 +384,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                                       acc[t][pt][4 * a4 + 3]};
                         const int cc0 = p.row_base + 32 * t + 8 * a4 + 4 * half;
                         if (p.dx && p.dx_accumulate && cc0 < p.row_split && cc0 < p.dx_channels) {
-                            const uint4 o = pre[(pt * MT + t) * 4 + a4];
+                            const uint2 o = pre[(pt * MT + t) * 4 + a4];
                             v[0] += __uint_as_float(o.x << 16), v[1] += __uint_as_float(o.x & 0xFFFF0000u);
                             v[2] += __uint_as_float(o.y << 16), v[3] += __uint_as_float(o.y & 0xFFFF0000u);
                             store4(static_cast<T*>(p.dx) + pixel * p.dx_cstride + cc0, v);
@@ -454,7 +477,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 pending = tile_ref(knext++);
                 stage_load(pending);
             }
-            prefetch_epilogue(cur);
+            // (the widest data-gradient kernel has no registers to hold these across its k-loop: it asks for
+            // them at the start of the finish phase, ahead of that phase's LDS writes)
+            if constexpr (!K::SWZ) prefetch_epilogue(cur);
             __builtin_amdgcn_s_setprio(0);
             STAMP(t1);
 #ifndef ISG_NO_MFMA  // diagnostic build without the k-loop: what the staging / epilogue structure alone takes
@@ -466,6 +491,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             done = cur;
             have_acc = true;
         } else {
+            if constexpr (K::SWZ) {
+                if (have_acc) prefetch_epilogue(done);
+            }
             stage_store(pending);  // requested two phases ago
             cur = pending;
             // the tile after that: requested BEFORE this phase's stores are issued, so that the
@@ -865,6 +893,9 @@ int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream
         return kNotSupported;
     }
     if (p.c0 == NG && p.c1 == 0 && mt == 1) return launch_pp<NG, 0, 1, 1, false>(p, num_cus, stream);
+#ifdef ISG_DGRAD_SWZ
+    if (p.c0 == NG && p.c1 == 0 && mt == 2) return launch_pp<NG, 0, 2, 1, false, 2>(p, num_cus, stream);
+#endif
     if (p.c0 == NG && p.c1 == 0 && mt == 2) return launch_pp<NG, 0, 2, 1, false, 1>(p, num_cus, stream);
     return kNotSupported;
 }
