@@ -5,6 +5,8 @@
 // HBM-bound: every element is read once and written once with 16-byte accesses.
 #include <hip/hip_bf16.h>
 
+#include <mutex>
+
 #include "isg_common.h"
 
 namespace {
@@ -116,6 +118,41 @@ int grid_for(long long nvec) {
     return (int)(want < kMaxPartialBlocks ? (want < 1 ? 1 : want) : kMaxPartialBlocks);
 }
 
+// Per-block partial sums of isg_relu_bwd_bias_static: a fixed array in the code object instead of a
+// caller's workspace, for callers that cannot allocate.  Every GPU the library runs on holds its own
+// copy (256 KiB) at its own address until the process ends.  In host code this name is only a handle
+// for hipGetSymbolAddress; kernels get the address that call returned.
+constexpr int kStaticMaxC = ISG_RELU_BWD_BIAS_STATIC_MAX_C;
+}  // namespace
+static __device__ __align__(256) float scratch[kMaxPartialBlocks * kStaticMaxC];
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_lock;
+float* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each device, 0 = not asked yet
+
+// The current device's copy of `scratch`; resolved once per device, with that device current.
+int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        isg::set_error("isg_relu_bwd_bias_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return ISG_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            isg::set_error("isg_relu_bwd_bias_static: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+            return ISG_ELAUNCH;
+        }
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return ISG_OK;
+}
+
 }  // namespace
 
 extern "C" int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, void* stream) {
@@ -140,11 +177,39 @@ extern "C" long long isg_relu_bwd_bias_workspace_bytes(int C) {
     return (long long)kMaxPartialBlocks * C * (long long)sizeof(float);
 }
 
+namespace {
+int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
+                         void* workspace, void* stream);
+}
+
 extern "C" int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                                  void* workspace, void* stream) {
     int rc = check("isg_relu_bwd_bias", n, C, dtype);
     if (rc != ISG_OK) return rc;
     ISG_REQUIRE(dbias && workspace, ISG_EINVAL, "isg_relu_bwd_bias: null pointer");
+    return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, workspace, stream);
+}
+
+// The partial sums go to this GPU's `scratch` array: no allocation, no workspace argument.  Every row the
+// reduction reads is written by the first kernel of the same call, so nothing has to be cleared between
+// calls; two calls in flight at once on one GPU (different streams) would share those rows and race.
+extern "C" int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, int dtype, void* dz,
+                                        float* dbias, void* stream) {
+    int rc = check("isg_relu_bwd_bias_static", n, C, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(C <= kStaticMaxC, ISG_EINVAL,
+                "isg_relu_bwd_bias_static: %d channels exceed the built-in scratch (at most %d); use "
+                "isg_relu_bwd_bias with a workspace", C, kStaticMaxC);
+    ISG_REQUIRE(dbias, ISG_EINVAL, "isg_relu_bwd_bias_static: null pointer");
+    float* partial = nullptr;
+    if ((rc = static_scratch(&partial)) != ISG_OK) return rc;
+    return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, partial, stream);
+}
+
+namespace {
+int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
+                         void* workspace, void* stream) {
+    int rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) return hipMemsetAsync(dbias, 0, sizeof(float) * C, s) == hipSuccess ? ISG_OK : ISG_ELAUNCH;
     ISG_REQUIRE(dy && y && dz, ISG_EINVAL, "isg_relu_bwd_bias: null pointer");
@@ -167,3 +232,4 @@ extern "C" int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int
     hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(C), dim3(kBlock), 0, s, partial, grid, C, dbias);
     return isg::check_launch("bias_partial_reduce_kernel");
 }
+}  // namespace

@@ -265,6 +265,16 @@ int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, voi
 long long isg_relu_bwd_bias_workspace_bytes(int C);
 int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                       void* workspace, void* stream);
+/* isg_relu_bwd_bias without the workspace argument and without any allocation: the per-workgroup partial
+ * sums live in an array built into the library (256 KiB per GPU, held until the process ends), whose
+ * address is looked up on the first call on each device.  No counterpart in the reference; it is for
+ * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  At most ISG_RELU_BWD_BIAS_STATIC_MAX_C channels (more: ISG_EINVAL);
+ * results are identical to isg_relu_bwd_bias.  All calls on one GPU share the array: calls that overlap
+ * on one GPU (different streams, different threads) race; calls queued on one stream do not. */
+#define ISG_RELU_BWD_BIAS_STATIC_MAX_C 64
+int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
+                             void* stream);
 
 /* ---- the encoder's first convolution -------------------------------------------------------------
  * KS x KS taps over a 3-channel image -> 32 channels, TensorFlow SAME padding ((KS-1)/2 before, the rest

@@ -1,0 +1,62 @@
+"""isg_relu_bwd_bias_static (the entry point that allocates nothing: its partial sums live in an array built
+into the library) against isg_relu_bwd_bias with a caller's workspace, through the C ABI: bit-identical dz
+and dbias on two calls in a row, the second on a smaller input, plus the size limit's error."""
+import pytest
+import torch
+
+from imagesegmentation_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(n, C, dtype, seed):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dy = torch.randn([n, C], generator=g).to(dtype).to(dev)
+    y = torch.randn([n, C], generator=g).clamp_min(0).to(dtype).to(dev)
+    lib = _lib.lib()
+    code = 0 if dtype == torch.float32 else 1
+    stream = _lib.current_stream()
+
+    ws = torch.full([lib.isg_relu_bwd_bias_workspace_bytes(C) // 4], float("nan"), device=dev)
+    dz_ref = torch.empty_like(dy)
+    db_ref = torch.empty([C], dtype=torch.float32, device=dev)
+    _lib.check(lib.isg_relu_bwd_bias(dy.data_ptr(), y.data_ptr(), n, C, code, dz_ref.data_ptr(), db_ref.data_ptr(),
+                                     ws.data_ptr(), stream), "isg_relu_bwd_bias")
+
+    dz = torch.empty_like(dy)
+    db = torch.empty([C], dtype=torch.float32, device=dev)
+    _lib.check(lib.isg_relu_bwd_bias_static(dy.data_ptr(), y.data_ptr(), n, C, code, dz.data_ptr(), db.data_ptr(),
+                                            stream), "isg_relu_bwd_bias_static")
+    torch.cuda.synchronize()
+    return (dz_ref, db_ref), (dz, db), (dy, y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_static_scratch_matches_the_workspace_form_on_two_calls_in_a_row(dtype):
+    # the first call fills every one of the 1,024 partial rows, the second uses far fewer of them: rows the
+    # first call left behind must not leak into the second result
+    for n, C, seed in ((300_000, 32, 1), (777, 16, 2)):
+        (dz_ref, db_ref), (dz, db), (dy, y) = _both(n, C, dtype, seed)
+        assert torch.equal(dz.view(torch.uint8), dz_ref.view(torch.uint8))
+        assert torch.equal(db, db_ref)
+        # and both against the definition (float64 sum; tolerance for the float accumulation order)
+        want_dz = torch.where(y > 0, dy, torch.zeros_like(dy))
+        assert torch.equal(dz, want_dz)
+        want_db = want_dz.double().sum(0)
+        assert torch.allclose(db.double(), want_db, rtol=1e-5, atol=1e-3)
+
+
+def test_static_scratch_size_limit_and_empty_input():
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    t = torch.zeros([8, 128], dtype=torch.bfloat16, device=dev)
+    db = torch.ones([128], dtype=torch.float32, device=dev)
+    rc = lib.isg_relu_bwd_bias_static(t.data_ptr(), t.data_ptr(), 8, 128, 1, t.data_ptr(), db.data_ptr(),
+                                      _lib.current_stream())
+    assert rc == -1 and b"at most 64" in lib.isg_last_error()
+    db16 = torch.ones([16], dtype=torch.float32, device=dev)
+    rc = lib.isg_relu_bwd_bias_static(None, None, 0, 16, 1, None, db16.data_ptr(), _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert float(db16.abs().sum()) == 0.0
