@@ -14,8 +14,10 @@ Also reported in the same line: IoU rollouts per second of the rasteriser (16,38
 masks materialised), per-kernel rooflines measured with events on the launch stream, and CPU baselines
 timed on the host cores in the same run (rank 0, N = 1 only).
 
-One process per GPU; for N > 1 launch through torch.distributed.run (RCCL all-reduce of the flat
-gradient bucket per step; the rasteriser shards rollouts with no collective).
+One process per GPU (RCCL all-reduce of the flat gradient bucket per step; the rasteriser shards rollouts
+with no collective).  `python bench.py --gpus N` with N > 1 starts its own N ranks through
+torch.distributed.run before anything touches a GPU and exits with their status; started under a launcher
+already (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import ctypes
@@ -52,6 +54,10 @@ def parse():
     ap.add_argument("--a3c-envs", type=int, default=1024, help="actor-critic environments per GPU (0 = skip)")
     ap.add_argument("--settle-seconds", type=float, default=8.0,
                     help="idle pause before the warm-up (see main: the after-effect of a process that just ended)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins the process group (ISG_DIST_BACKEND, default nccl), runs the "
+                         "timed region's fences and reductions around an empty step on host tensors, and rank 0 prints "
+                         "a JSON line - checks the multi-rank launch path on a machine without GPUs")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -336,17 +342,65 @@ def note(msg):
 _T0 = time.perf_counter()
 
 
+def self_launch(n):
+    """Starts n ranks of this script (same arguments) as children through torch.distributed.run and returns their
+    exit status.  Called before this process has touched a GPU; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def launch_check(args, world, rank):
+    """The collectives of the timed region (barrier fences, MAX over ranks of the elapsed time, SUM of a per-rank
+    rate) on host tensors, no GPU: what --launch-check runs."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("ISG_DIST_BACKEND", "gloo"))
+    if os.environ.get("ISG_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit("rank %d asked to fail (ISG_BENCH_FAIL_RANK)" % rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks = torch.ones([1], dtype=torch.float64)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no GPU work)", "value": args.batch * world * args.steps / elapsed,
+                          "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "ranks_seen": int(ranks.item()),
+                          "launch_check": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if os.environ.get("ISG_BENCH_WATCHDOG"):  # dump every thread's stack and exit if the run takes this long
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ISG_BENCH_WATCHDOG"]), exit=True)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+        raise SystemExit("--gpus %d does not match the %d ranks of the launcher" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, world, rank)
     # rehearsal on a box with fewer GPUs than ranks: ISG_DIST_BACKEND=gloo lets several ranks share a device
     backend = os.environ.get("ISG_DIST_BACKEND", "nccl")
     if backend != "nccl":

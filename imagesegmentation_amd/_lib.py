@@ -23,6 +23,7 @@ SIGNATURES = {
     "isg_raster_iou": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "isg_shape_mask": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_history_frames": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _int, _vp]),
+    "isg_batch_points": (_int, [_vp, _vp, _int, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "isg_env_step": (_int, [_vp, _vp, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _int, _int, _vp, _vp, _vp, _int, _int,
                             _vp]),
     "isg_softmax_xent_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
     "isg_sample_actions": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int, _vp, _vp]),
+    "isg_decode_step": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _int, _vp]),
     "isg_sequence_metrics": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),

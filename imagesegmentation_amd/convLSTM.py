@@ -527,7 +527,7 @@ def _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state):
     return torch.stack(outs, dim=1), tuple(state)
 
 
-def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True, output_pool=1):
+def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True, output_pool=1, steps=None):
     """``tf.nn.dynamic_rnn`` for a ``MultiRNNCell`` (or a single cell) of ConvLSTM cells.
 
     inputs: a time-major tensor [T, B, H, W, C] (``time_major=False``: [B, T, H, W, C]) or a
@@ -536,6 +536,8 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
     Returns (outputs, final_state); outputs are [T, B, H, W, F] when time_major else [B, T, H, W, F].
     ``output_pool`` = k > 1 (not in TensorFlow): the outputs come back averaged over k x k windows,
     [.., H/k, W/k, F], and the pool's gradient is applied inside the recurrence's backward sweep.
+    ``steps`` (not in TensorFlow): an upper bound of the lengths known to the caller, for lengths given as a
+    device tensor - that many steps run instead of fetching the longest length from the device.
     """
     multi = cell if isinstance(cell, MultiRNNCell) else MultiRNNCell([cell])
     if isinstance(inputs, SequenceInput):
@@ -551,7 +553,12 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
     if sequence_length is None:
         durations_dev, t_run = None, T
     else:
-        if torch.is_tensor(sequence_length):
+        if torch.is_tensor(sequence_length) and steps is not None:
+            # lengths that live on the device stay there: `steps` steps run and the kernels mask per sample
+            # (asking the device for the longest length stalls the host until the stream has drained)
+            t_run = int(steps) if sequence_length.numel() else 0
+            durations_dev = sequence_length.to(device=dev, dtype=torch.int32).contiguous()
+        elif torch.is_tensor(sequence_length):
             host = sequence_length.detach().cpu()
             t_run = int(host.max()) if host.numel() else 0
             durations_dev = sequence_length.to(device=dev, dtype=torch.int32).contiguous()
@@ -579,7 +586,14 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
         tensors += [c, h]
     for c in multi.cells:
         tensors += [c.input_to_state_kernel, c.hidden_to_state_kernel, c.bias]
-    flat = _SequenceFunction.apply(multi, seq, durations_dev, t_run, int(output_pool), *tensors)
+    if not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors):
+        # nothing will run backward (validation, decode): no gate tensors, two alternating state buffers per
+        # layer instead of T saved ones; the final state lives in buffers private to this call
+        out, fin, _ = _run_sequence_forward(list(multi.cells), seq, durations_dev, t_run, list(initial_state), False,
+                                            int(output_pool))
+        flat = [out] + [s for cf, hf in fin for s in (cf, hf)]
+    else:
+        flat = _SequenceFunction.apply(multi, seq, durations_dev, t_run, int(output_pool), *tensors)
     out = flat[0]
     final = tuple(LSTMStateTuple(flat[1 + 2 * l], flat[2 + 2 * l]) for l in range(len(multi.cells)))
     if time_major:

@@ -55,14 +55,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void xent_fwd_kernel(const T* 
     int bi = 0x7fffffff;
     for (int c = lane; c < cols; c += 64) {
         const float v = ld(z, c);
-        if (v > bv) {  // strictly greater: within a lane columns come in increasing order
+        // strictly greater: within a lane columns come in increasing order.  The lane's first column always
+        // becomes its candidate, so a row of -inf (or NaN) still reports a column of the row, the first one
+        if (v > bv || bi == 0x7fffffff) {
             bv = v;
             bi = c;
         }
         if (v > m) {
             s = s * expf(m - v) + 1.0f;
             m = v;
-        } else {
+        } else if (v != -INFINITY) {  // a masked logit (-inf) adds nothing; exp(-inf - -inf) would be NaN
             s += expf(v - m);
         }
     }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sample_kernel(const T* __
         const uint32_t r = mix32(key + (uint32_t)c * 0xc2b2ae35U);
         const float u = ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
         const float v = ld(z, c) - logf(-logf(u));
-        if (v > bv) {
+        if (v > bv || bi == 0x7fffffff) {  // a row of -inf still yields one of its columns
             bv = v;
             bi = c;
         }
@@ -148,6 +150,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sample_kernel(const T* __
         } else {
             out_idx[row] = bi;
         }
+    }
+}
+
+// One step of the autoregressive decode loop for every sample, after the head: the argmax class of the row (first
+// maximum), its vertex (x, y) = (class / P, class % P), then the stop rule, the predicted polygon and the history
+// points of the next step - everything the host loop of the reference does between two session runs.
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void decode_step_kernel(
+    const T* __restrict__ logits, int rows, int cols, int P, int end_token, const int* __restrict__ close_xy,
+    int* __restrict__ required, int* __restrict__ durations, int* __restrict__ predicted, int Tmax, int step,
+    int* __restrict__ history, int hist) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = ld(z, c);
+        if (v > bv || bi == 0x7fffffff) {
+            bv = v;
+            bi = c;
+        }
+    }
+    wave_argmax(bv, bi);
+    if (lane != 0) return;
+    const int x = bi / P, y = bi - x * P;
+    durations[row] += required[row];
+    const int cx = close_xy[2 * row], cy = close_xy[2 * row + 1];
+    int px = x, py = y;  // the vertex filed in the predicted polygon
+    int fx = x, fy = y;  // the point the next step's newest history frame shows
+    if (end_token) {
+        if (x == P && y == 0) {  // the end token closes the polygon; the frame shows pixel (0, 0)
+            required[row] = 0;
+            px = cx, py = cy;
+            fx = 0, fy = 0;
+        }
+    } else if (x == cx && y == cy) {
+        required[row] = 0;
+    }
+    predicted[((size_t)row * Tmax + step) * 2] = px;
+    predicted[((size_t)row * Tmax + step) * 2 + 1] = py;
+    if (hist > 0) {  // np.roll(+1) over the frames, then the newest frame is overwritten
+        int* hp = history + (size_t)row * hist * 2;
+        const int lx = hp[2 * (hist - 1)], ly = hp[2 * (hist - 1) + 1];
+        for (int i = hist - 1; i > 0; --i) hp[2 * i] = hp[2 * (i - 1)], hp[2 * i + 1] = hp[2 * (i - 1) + 1];
+        hp[0] = lx, hp[1] = ly;
+        hp[2 * (hist - 1)] = fx, hp[2 * (hist - 1) + 1] = fy;
     }
 }
 
@@ -274,6 +324,28 @@ extern "C" int isg_sample_actions(const void* logits, int rows, int cols, int dt
                 P, P);
     return launch_sample("isg_sample_actions", logits, rows, cols, dtype, seed, row_offset, row_offset_dev, P, out_xy,
                          stream);
+}
+
+extern "C" int isg_decode_step(const void* logits, int rows, int cols, int dtype, int P, int end_token,
+                               const int32_t* close_xy, int32_t* required, int32_t* durations, int32_t* predicted,
+                               int T, int step, int32_t* history_points, int hist, void* stream) {
+    int rc = check_rows("isg_decode_step", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(P >= 1 && cols <= P * P + P && hist >= 0 && T >= 1 && step >= 0 && step < T, ISG_EINVAL,
+                "isg_decode_step: cols=%d P=%d hist=%d step=%d T=%d", cols, P, hist, step, T);
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && close_xy && required && durations && predicted && (hist == 0 || history_points), ISG_EINVAL,
+                "isg_decode_step: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(decode_step_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), rows, cols, P,
+                           end_token, close_xy, required, durations, predicted, T, step, history_points, hist);
+    else
+        hipLaunchKernelGGL(decode_step_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), rows, cols, P, end_token, close_xy, required,
+                           durations, predicted, T, step, history_points, hist);
+    return isg::check_launch("decode_step_kernel");
 }
 
 extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T,

@@ -1,5 +1,8 @@
-// One-hot history frames on device: frames[n][y][x][i] = 1 where (x, y) == points[n][i].
-// Write-only, 16 B per lane where the row of channels allows it.
+// History frames, environment steps, the teacher-forcing batch builder and the decode step: the small integer
+// kernels around the recurrence.
+// history_frames_kernel: frames[n][y][x][i] = 1 where (x, y) == points[n][i]; write-only, one thread per pixel
+// writing that pixel's `hist` channels (the frames usually land beside other channels of a state tensor, so the
+// stride between pixels is the caller's and the stores are element-sized).
 #include <hip/hip_bf16.h>
 
 #include "isg_common.h"
@@ -68,7 +71,75 @@ __global__ __launch_bounds__(256) void env_step_kernel(const int* __restrict__ a
     if (terminal) done[e] = 1;
 }
 
+// One thread per (sample, slot): slot t < T writes step t's history points and target, slot k < vcap writes
+// rolled vertex k.  np.roll(v, s) puts v[(k - s) mod n] at position k.
+__global__ __launch_bounds__(256) void batch_points_kernel(const int* __restrict__ table, const int* __restrict__ counts,
+                                                           int vcap, const int* __restrict__ indices,
+                                                           const int* __restrict__ starts, int B, int T, int hist, int P,
+                                                           int end_token, int* __restrict__ durations,
+                                                           int* __restrict__ points, int* __restrict__ targets,
+                                                           int* __restrict__ rolled, int* __restrict__ nverts) {
+    const int slots = T > vcap ? T : vcap;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * slots) return;
+    const int b = gid / slots, slot = gid - b * slots;
+    const int sample = indices[b];
+    const int n = counts[sample];
+    const int* v = table + (size_t)sample * vcap * 2;
+    // floor modulo: start vertices may be given negative or beyond n, as np.roll takes them
+    const int s = ((starts[b] % n) + n) % n;
+    auto vertex = [&](int k, int& x, int& y) {  // rolled vertex k mod n
+        int r = ((k % n) + n) % n - s;
+        r = r < 0 ? r + n : r;
+        x = v[2 * r], y = v[2 * r + 1];
+    };
+    const int dur = n - hist + 1;
+    const int filled = dur < T ? dur : T;  // steps the reference's loop writes
+    if (slot == 0) {
+        durations[b] = dur;
+        if (nverts) nverts[b] = n;
+    }
+    if (slot < T) {
+        const int t = slot;
+        const bool live = t < filled;
+        for (int i = 0; i < hist; ++i) {
+            int x = -1, y = -1;
+            if (live) vertex(t - hist + i + 1, x, y);
+            int* d = points + (((size_t)b * T + t) * hist + i) * 2;
+            d[0] = x, d[1] = y;
+        }
+        int tx = 0, ty = 0;
+        if (live) vertex(t + 1, tx, ty);
+        const int last = filled > 0 ? filled - 1 : 0;
+        if (end_token && t == last) tx = P, ty = 0;
+        targets[((size_t)b * T + t) * 2] = tx;
+        targets[((size_t)b * T + t) * 2 + 1] = ty;
+    }
+    if (rolled && slot < vcap) {
+        int x = 0, y = 0;
+        if (slot < n) vertex(slot, x, y);
+        rolled[((size_t)b * vcap + slot) * 2] = x;
+        rolled[((size_t)b * vcap + slot) * 2 + 1] = y;
+    }
+}
+
 }  // namespace
+
+extern "C" int isg_batch_points(const int32_t* table, const int32_t* counts, int vcap, const int32_t* indices,
+                                const int32_t* starts, int B, int T, int hist, int P, int end_token,
+                                int32_t* durations, int32_t* points, int32_t* targets, int32_t* rolled, int32_t* nverts,
+                                void* stream) {
+    ISG_REQUIRE(B >= 0 && T >= 1 && hist >= 0 && vcap >= 1 && P >= 1, ISG_EINVAL, "isg_batch_points: bad sizes");
+    if (B == 0) return ISG_OK;
+    ISG_REQUIRE(table && counts && indices && starts && durations && targets && (hist == 0 || points), ISG_EINVAL,
+                "isg_batch_points: null pointer");
+    const long long threads = (long long)B * (T > vcap ? T : vcap);
+    ISG_REQUIRE(threads < (1LL << 31), ISG_EINVAL, "isg_batch_points: batch too large");
+    hipLaunchKernelGGL(batch_points_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), table, counts, vcap, indices, starts, B, T, hist, P, end_token,
+                       durations, points, targets, rolled, nverts);
+    return isg::check_launch("batch_points_kernel");
+}
 
 extern "C" int isg_env_step(const int32_t* actions, const int32_t* true_vertices, int true_stride, int32_t* predicted,
                             int vcap, int32_t* num_predicted, int32_t* history_points, int hist, uint8_t* done, int n,

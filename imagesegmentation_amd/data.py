@@ -1,63 +1,90 @@
-"""Synthetic polygons and teacher-forcing batches with the reference's recipe and batch layout.
+"""Synthetic polygons and teacher-forcing batches: the reference's recipe, random-draw order and batch
+contract, built around index arithmetic that runs the same way on the host (NumPy) and on the GPU.
 
-* ``create_valid_polygon`` / ``reduce_polygon`` / ``get_angle``: the generator recipe of reference
-  generate_polygons.py:11-54 (random points -> convex hull -> drop near-straight vertices -> fill,
-  rejection on area and edge lengths), including its quirks: the area is counted over the
-  3-channel image, and ``reduce_polygon`` keeps iterating over the vertex list it started a pass with
-  while deleting from the shrinking copy.  The lossy JPEG round trip of the reference's dataset
-  (generate_polygons.py:75, Dataset.py:68) is skipped: images stay clean {0, 1}.
-* ``PolygonDataset``: ``get_batch_for_rnn`` and ``raw_sample`` with the reference's tuple layout
-  (reference Dataset.py:104-162, EndTokenDataset.py:104-164), plus ``get_batch_points`` which hands
-  the history out as vertex points [B, T, hist, 2] instead of dense one-hot frames, so that the
-  frames are rendered on the GPU and a 224 x 224 batch does not move half a gigabyte of float64.
+What is a contract here (checked against outputs recorded from the reference, tests/test_data.py):
+
+* generator (reference generate_polygons.py:11-54): ONE ``np.random.randint(0, S, [10, 2])`` per attempt ->
+  convex hull -> near-straight vertices removed -> filled mask x 3 channels -> accepted when the area (counted
+  over the three channels) and the shortest / longest edge pass.  Equal seeds give equal polygons.  The
+  vertex removal applies each pass's deletions BY POSITION to an array that shrinks while the positions stay
+  those of the pass's start (the reference deletes from a rebound copy while it enumerates the original); a
+  position that has fallen off the end is an ``IndexError``, which like any failure of an attempt means
+  "draw again".  The lossy JPEG round trip of the reference's files (generate_polygons.py:75, Dataset.py:68)
+  is skipped: images stay clean {0, 1}.
+* batches (reference Dataset.py:104-162, EndTokenDataset.py:104-164): ``np.random.choice`` of the samples,
+  then one ``np.random.randint(n)`` start vertex per sample in batch order; tuple ``(durations, images,
+  histories, targets, vertices)``; ``duration = n - hist + 1``; frame i of step t shows rolled vertex
+  ``t - hist + i + 1``; target of step t is rolled vertex ``t + 1``; with an end token the target of the
+  last filled step is ``(P, 0)`` (EndTokenDataset.py:150).
+
+``PolygonDataset`` keeps every polygon in one padded vertex table, so a batch is a gather:
+``sequence_points`` (host) and ``DeviceBatchBuilder`` (isg_batch_points, one launch) evaluate the same
+``(t, i, start) -> vertex`` formula.  Dense one-hot frames [B, T, P, P, hist] - the reference's feed - are
+rendered from the points only when asked for (``get_batch_for_rnn``).
 """
 import numpy as np
 import scipy.spatial
 
-from .util import create_history, iterate_in_ntuples
+from .util import iterate_in_ntuples  # noqa: F401  (part of this module's surface, as in the reference's `from util import *`)
+
+
+# ---- generator -------------------------------------------------------------------------------------------------
+def corner_angles(ring):
+    """Angle in degrees at every vertex of a closed ring [V, 2], between its two neighbours."""
+    ring = np.asarray(ring)
+    to_prev = np.roll(ring, 1, axis=0) - ring
+    to_next = np.roll(ring, -1, axis=0) - ring
+    dots = (to_prev * to_next).sum(axis=1)
+    norms = np.sqrt((to_prev * to_prev).sum(axis=1)) * np.sqrt((to_next * to_next).sum(axis=1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.degrees(np.arccos(dots / norms))
 
 
 def get_angle(a, b, c):
     """Angle a-b-c in degrees (reference generate_polygons.py:33-41)."""
-    ba, bc = a - b, c - b
-    cosine = np.dot(ba, bc) / (np.linalg.norm(ba) * np.linalg.norm(bc))
-    return np.degrees(np.arccos(cosine))
+    return float(corner_angles(np.stack([np.asarray(a), np.asarray(b), np.asarray(c)]))[1])
 
 
 def reduce_polygon(verts, eps):
-    """Deletes vertices whose interior angle is within eps of 180 degrees
-    (reference generate_polygons.py:44-54).  As there, a pass enumerates the vertex array it started
-    with while deletions hit the current, shorter array."""
-    again = True
-    while again:
-        again = False
-        for i, (a, b, c) in enumerate(iterate_in_ntuples(verts, n=3, offset=-1)):
-            if abs(180 - get_angle(a, b, c)) < eps:
-                verts = np.delete(verts, i, 0)
-                again = True
-    return verts
+    """Removes vertices whose corner is within ``eps`` degrees of straight, pass after pass until none is
+    (reference generate_polygons.py:44-54), with the reference's by-position deletion (module docstring)."""
+    ring = np.asarray(verts)
+    while True:
+        straight = np.flatnonzero(np.abs(180 - corner_angles(ring)) < eps)
+        if straight.size == 0:
+            return ring
+        survivors = list(range(len(ring)))
+        for position in straight:
+            if position >= len(survivors):
+                raise IndexError("index %d is out of bounds for axis 0 with size %d" % (position, len(survivors)))
+            del survivors[position]
+        ring = ring[survivors]
+
+
+def _attempt(image_size, shape_complexity, reduction_tolerance, shape_mask_fn):
+    """One draw of the generator: (ring [V, 2] int, mask [S, S]); raises when the draw is degenerate."""
+    cloud = np.random.randint(0, image_size, [shape_complexity, 2])
+    ring = cloud[scipy.spatial.ConvexHull(cloud).vertices]
+    ring = reduce_polygon(ring, eps=reduction_tolerance)
+    return ring, shape_mask_fn(ring, image_size)
 
 
 def create_valid_polygon(image_size, shape_complexity, min_area, min_distance, max_distance, reduction_tolerance,
                          shape_mask_fn=None):
-    """(vertices / image_size, image [S, S, 3]) of one accepted polygon; draws from ``np.random``
-    exactly as reference generate_polygons.py:11-30 does, so equal seeds give equal polygons."""
+    """(vertices / image_size, image [S, S, 3]) of the first accepted draw; consumes ``np.random`` exactly as
+    reference generate_polygons.py:11-30 does."""
     if shape_mask_fn is None:
         from .util import create_shape_mask as shape_mask_fn
     while True:
         try:
-            points = np.random.randint(0, image_size, [shape_complexity, 2])
-            hull = scipy.spatial.ConvexHull(points)
-            poly_verts = np.array([(points[s, 0], points[s, 1]) for s in hull.vertices])
-            poly_verts = reduce_polygon(poly_verts, eps=reduction_tolerance)
-            image = np.stack([shape_mask_fn(poly_verts, image_size) for _ in range(3)], axis=2)
-        except Exception:
+            ring, mask = _attempt(image_size, shape_complexity, reduction_tolerance, shape_mask_fn)
+        except Exception:  # degenerate hull, a vertex dropped off the ring, a pixel outside the image: draw again
             continue
-        area = np.count_nonzero(image)  # over 3 channels, as in the reference
-        distances = [np.linalg.norm(b - a) for a, b in iterate_in_ntuples(poly_verts, n=2)]
-        if area > min_area and min(distances) > min_distance and max(distances) < max_distance:
-            break
-    return poly_verts / image_size, image
+        edges = np.roll(ring, -1, axis=0) - ring
+        lengths = np.sqrt((edges * edges).sum(axis=1))
+        area = 3 * int(np.count_nonzero(mask))  # the reference counts over the 3-channel image
+        if area > min_area and lengths.min() > min_distance and lengths.max() < max_distance:
+            return ring / image_size, np.repeat(mask[:, :, None], 3, axis=2)
 
 
 def generate_polygons(count, image_size, seed, shape_mask_fn=None):
@@ -65,13 +92,45 @@ def generate_polygons(count, image_size, seed, shape_mask_fn=None):
     thresholds 5 / 100 scale with image_size / 28.  Returns (images [N,S,S,3] float64, list of
     normalised vertex arrays)."""
     np.random.seed(seed)
-    s = image_size / 28.0
-    images, verts = [], []
-    for _ in range(count):
-        v, img = create_valid_polygon(image_size, 10, 10, 5 * s, 100 * s, 20, shape_mask_fn)
-        images.append(img)
-        verts.append(v)
-    return np.stack(images).astype(np.float64), verts
+    unit = image_size / 28.0
+    drawn = [create_valid_polygon(image_size, 10, 10, 5 * unit, 100 * unit, 20, shape_mask_fn) for _ in range(count)]
+    return np.stack([image for _, image in drawn]).astype(np.float64), [ring for ring, _ in drawn]
+
+
+# ---- batches ----------------------------------------------------------------------------------------------------
+def sequence_points(table, counts, indices, starts, max_timesteps, history_length, prediction_size, end_token):
+    """The teacher-forcing sequences of samples ``indices`` rolled to start vertices ``starts``, as a gather from
+    the padded vertex ``table`` int [N, vcap, 2] (``counts`` [N] vertices each).
+
+    np.roll(v, s) puts v[(k - s) mod n] at position k, so rolled vertex k of a sample is table row
+    ``(k - s) mod n``.  Returns (durations int32 [B], points int32 [B, T, hist, 2] with (-1, -1) for frames of
+    steps that are not filled, targets int32 [B, T, 2])."""
+    indices = np.asarray(indices, np.int64)
+    T, hist = int(max_timesteps), int(history_length)
+    n = counts[indices].astype(np.int64)[:, None, None]
+    s = np.asarray(starts, np.int64)[:, None, None]
+    t = np.arange(T)[None, :, None]
+    i = np.arange(hist)[None, None, :]
+    durations = (n - hist + 1)[:, 0, 0]
+    filled = t < np.minimum(durations, T)[:, None, None]  # steps the reference's loop writes
+    row = indices[:, None, None]
+    points = table[row, ((t - hist + i + 1) % n - s) % n].astype(np.int32)
+    points[~np.broadcast_to(filled, points.shape[:3])] = -1
+    targets = table[row[:, :, 0], (((t + 1) % n - s) % n)[:, :, 0]].astype(np.int32)
+    targets[~filled[:, :, 0]] = 0
+    if end_token:
+        last = np.maximum(np.minimum(durations, T) - 1, 0)
+        targets[np.arange(len(indices)), last] = (prediction_size, 0)
+    return durations.astype(np.int32), points, targets
+
+
+def frames_from_points(points, prediction_size, dtype=np.float64):
+    """Dense one-hot frames [B, T, P, P, hist] (index [y, x]) of int points [B, T, hist, 2]."""
+    B, T, hist, _ = points.shape
+    frames = np.zeros([B, T, prediction_size, prediction_size, hist], dtype=dtype)
+    b, t, i = np.nonzero(points[..., 0] >= 0)
+    frames[b, t, points[b, t, i, 1], points[b, t, i, 0], i] = 1
+    return frames
 
 
 class PolygonDataset:
@@ -89,15 +148,19 @@ class PolygonDataset:
         self._prediction_size = prediction_size
         self._history_length = history_length
         self._end_token = end_token
+        self._counts = np.array([len(v) for v in vertices], np.int32)
+        self._table = np.zeros([len(vertices), max(int(self._counts.max(initial=1)), 1), 2], np.int32)
+        for k, v in enumerate(vertices):
+            self._table[k, :len(v)] = v
 
     @classmethod
     def synthetic(cls, count, image_size, prediction_size, max_timesteps, history_length, seed=0, end_token=False,
                   shape_mask_fn=None):
-        images, verts = generate_polygons(count, image_size, seed, shape_mask_fn)
-        vs = np.empty([count], dtype=object)
-        for i, v in enumerate(verts):
-            vs[i] = np.floor(v * prediction_size).astype(int)
-        return cls(images, vs, max_timesteps, prediction_size, history_length, end_token)
+        images, rings = generate_polygons(count, image_size, seed, shape_mask_fn)
+        vertices = np.empty([count], dtype=object)
+        for k, ring in enumerate(rings):
+            vertices[k] = np.floor(ring * prediction_size).astype(int)
+        return cls(images, vertices, max_timesteps, prediction_size, history_length, end_token)
 
     def __len__(self):
         assert self._images.shape[0] == self._vertices.shape[0]
@@ -107,50 +170,87 @@ class PolygonDataset:
     def image_size(self):
         return self._image_size
 
-    def _sequence(self, poly_verts, start_idx=None, dense=True):
-        n = len(poly_verts)
-        hist, T, P = self._history_length, self._max_timesteps, self._prediction_size
-        start_idx = np.random.randint(n) if start_idx is None else start_idx
-        poly_verts = np.roll(poly_verts, start_idx, axis=0)
-        histories = np.zeros([T, P, P, hist], dtype=np.uint16) if dense else np.full([T, hist, 2], -1, np.int32)
-        targets = np.zeros([T, 2], dtype=np.int32)
-        idx = 0
-        for idx in range(min(n - hist + 1, T)):
-            if dense:
-                histories[idx] = create_history(poly_verts, idx, hist, P)
-            else:
-                for i in range(hist):
-                    histories[idx, i] = poly_verts[(idx - hist + i + 1) % n]
-            targets[idx, :] = np.array(poly_verts[(idx + 1) % n])
-        if self._end_token:
-            targets[idx, :] = np.array([P, 0])
-        return n - hist + 1, histories, targets, poly_verts
+    # The random part of a batch, in the reference's order: which samples, then each one's start vertex.
+    def draw(self, batch_size, start_idx=None):
+        indices = np.random.choice(self._images.shape[0], batch_size, replace=False)
+        if start_idx is None:
+            starts = np.array([np.random.randint(self._counts[k]) for k in indices], np.int64).reshape(-1)
+        else:
+            starts = np.full([batch_size], start_idx, np.int64)
+        return indices, starts
 
-    def _batch(self, batch_size, start_idx, dense):
-        hist, T, P = self._history_length, self._max_timesteps, self._prediction_size
-        batch_indices = np.random.choice(self._images.shape[0], batch_size, replace=False)
-        batch_d = np.zeros([batch_size], dtype=np.int32)
-        batch_images = self._images[batch_indices]
-        batch_h = np.zeros([batch_size, T, P, P, hist]) if dense else np.zeros([batch_size, T, hist, 2], np.int32)
-        batch_t = np.zeros([batch_size, T, 2], dtype=np.int32)
-        batch_vertices = self._vertices[batch_indices]
-        for i, vertices in enumerate(batch_vertices):
-            batch_d[i], batch_h[i], batch_t[i], batch_vertices[i] = self._sequence(vertices, start_idx, dense)
-        return batch_d, batch_images, batch_h, batch_t, batch_vertices
+    def rolled_vertices(self, indices, starts):
+        out = np.empty([len(indices)], dtype=object)
+        for k, (sample, start) in enumerate(zip(indices, starts)):
+            out[k] = np.roll(self._vertices[sample], int(start), axis=0)
+        return out
+
+    def get_batch_points(self, batch_size=8, start_idx=None):
+        """(durations [B], images [B,S,S,3], points int32 [B,T,hist,2] with (-1,-1) = empty frame, targets
+        [B,T,2], vertices): the reference's tuple with the history as vertex points."""
+        indices, starts = self.draw(batch_size, start_idx)
+        durations, points, targets = sequence_points(self._table, self._counts, indices, starts, self._max_timesteps,
+                                                     self._history_length, self._prediction_size, self._end_token)
+        return durations, self._images[indices], points, targets, self.rolled_vertices(indices, starts)
 
     def get_batch_for_rnn(self, batch_size=8, start_idx=None):
         """(durations [B], images [B,S,S,3], histories [B,T,P,P,hist], targets [B,T,2], vertices)."""
-        return self._batch(batch_size, start_idx, True)
-
-    def get_batch_points(self, batch_size=8, start_idx=None):
-        """Same tuple with histories as int32 points [B,T,hist,2] ((-1,-1) = empty frame)."""
-        return self._batch(batch_size, start_idx, False)
+        durations, images, points, targets, vertices = self.get_batch_points(batch_size, start_idx)
+        return durations, images, frames_from_points(points, self._prediction_size), targets, vertices
 
     def raw_sample(self, batch_size):
         """(images, vertices) with a random start vertex per polygon (Dataset.py:152-162)."""
-        batch_indices = np.random.choice(self._images.shape[0], batch_size, replace=False)
-        batch_images = self._images[batch_indices]
-        batch_verts = np.empty([batch_size], dtype=object)
-        for i, p in enumerate(self._vertices[batch_indices]):
-            batch_verts[i] = np.roll(p, np.random.randint(len(p)), axis=0)
-        return batch_images, batch_verts
+        indices, starts = self.draw(batch_size)
+        return self._images[indices], self.rolled_vertices(indices, starts)
+
+
+class DeviceBatchBuilder:
+    """The batch builder with the dataset resident on the GPU: images, the padded vertex table and the counts are
+    uploaded once; a batch is one gather of the images plus ONE isg_batch_points launch that writes durations,
+    history points, targets and the rolled polygons.  Nothing of size B x T x P x P is ever built, and the only
+    host work per batch is the random draw (the reference's ``np.random`` calls, so that equal seeds give the
+    batches ``PolygonDataset.get_batch_points`` gives) or none at all with ``device_draw=True``."""
+
+    def __init__(self, dataset, device, image_dtype=None):
+        import torch
+        from . import ops
+        self.dataset = dataset
+        self.device = torch.device(device)
+        images = torch.as_tensor(dataset._images)
+        self.images = images.to(self.device, dtype=image_dtype if image_dtype is not None else images.dtype)
+        self.table = ops.upload(dataset._table, self.device, torch.int32).contiguous()
+        self.counts = ops.upload(dataset._counts, self.device, torch.int32).contiguous()
+        self._generator = None
+
+    def build(self, indices, starts):
+        """indices / starts: host arrays or device int tensors [B]."""
+        import torch
+        from . import ops
+        ds = self.dataset
+        indices = ops.upload(np.asarray(indices), self.device, torch.int32) if not torch.is_tensor(indices) \
+            else indices.to(self.device, torch.int32)
+        starts = ops.upload(np.asarray(starts), self.device, torch.int32) if not torch.is_tensor(starts) \
+            else starts.to(self.device, torch.int32)
+        durations, points, targets, rolled, nverts = ops.batch_points(
+            self.table, self.counts, indices, starts, ds._max_timesteps, ds._history_length, ds._prediction_size,
+            ds._end_token)
+        images = self.images.index_select(0, indices.long())
+        return dict(durations=durations, images=images, points=points, targets=targets, vertices=rolled,
+                    nverts=nverts)
+
+    def get_batch_points(self, batch_size=8, start_idx=None, device_draw=False, seed=0):
+        """``device_draw``: samples and start vertices are drawn on the GPU (its own generator, seeded once with
+        ``seed``): no host work per batch, not the reference's random stream."""
+        if not device_draw:
+            return self.build(*self.dataset.draw(batch_size, start_idx))
+        import torch
+        if self._generator is None:
+            self._generator = torch.Generator(device=self.device)
+            self._generator.manual_seed(int(seed))
+        n = self.images.shape[0]
+        indices = torch.randperm(n, device=self.device, generator=self._generator)[:batch_size].to(torch.int32)
+        u = torch.rand([batch_size], device=self.device, generator=self._generator)
+        counts = self.counts.index_select(0, indices.long())
+        starts = torch.minimum((u * counts).to(torch.int32), counts - 1) if start_idx is None else \
+            torch.full([batch_size], int(start_idx), dtype=torch.int32, device=self.device)
+        return self.build(indices, starts)

@@ -44,6 +44,13 @@ def weights_epoch():
     return _weights_epoch
 
 
+def note_weights_changed():
+    """For code that writes parameters through views torch does not track (checkpoint restore into the flat
+    buffer): invalidates everything cached from parameter values."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
 def adam_tf_(param, m, v, grad, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_norm=None, clip_norm=None):
     """One TensorFlow-form Adam step over flat float32 buffers in one launch (isg_adam_tf); with ``clip_norm``
     the gradient is scaled by clip_norm / max(grad_norm, clip_norm) on the fly (grad_norm: device scalar)."""
@@ -443,3 +450,26 @@ def conv32_wgrad(x, dz, ks):
                                      _lib.current_stream())
     _lib.check(rc, "isg_conv32_wgrad")
     return dw
+
+
+# ---- teacher-forcing batch builder -------------------------------------------------------------------------
+def batch_points(table, counts, indices, starts, max_timesteps, hist, prediction_size, end_token):
+    """isg_batch_points: (durations [B], points [B,T,hist,2], targets [B,T,2], rolled vertices [B,vcap,2],
+    vertex counts [B]), all int32 device tensors, for samples ``indices`` rolled to ``starts`` of the padded vertex
+    ``table`` int32 [N,vcap,2] / ``counts`` int32 [N]."""
+    _need_cuda(table, "table")
+    for t in (table, counts, indices, starts):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    B, T, vcap = indices.shape[0], int(max_timesteps), table.shape[1]
+    dev = table.device
+    durations = torch.empty([B], dtype=torch.int32, device=dev)
+    points = torch.empty([B, T, int(hist), 2], dtype=torch.int32, device=dev)
+    targets = torch.empty([B, T, 2], dtype=torch.int32, device=dev)
+    rolled = torch.empty([B, vcap, 2], dtype=torch.int32, device=dev)
+    nverts = torch.empty([B], dtype=torch.int32, device=dev)
+    rc = _lib.lib().isg_batch_points(_lib.ptr(table), _lib.ptr(counts), vcap, _lib.ptr(indices), _lib.ptr(starts), B, T,
+                                     int(hist), int(prediction_size), int(bool(end_token)), _lib.ptr(durations),
+                                     _lib.ptr(points), _lib.ptr(targets), _lib.ptr(rolled), _lib.ptr(nverts),
+                                     _lib.current_stream())
+    _lib.check(rc, "isg_batch_points")
+    return durations, points, targets, rolled, nverts

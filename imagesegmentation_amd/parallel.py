@@ -18,6 +18,14 @@ def rank(group=None):
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
 
+def sampling_seed(base, group=None):
+    """Seed of a rank's own random draws (sampled actions): base * world + rank, distinct per rank for every
+    base, and equal to ``base`` for a single process.  Weights are initialised from the un-folded seed (every
+    rank must hold the same ones); rollouts must NOT share their noise across ranks, or the all-reduced policy
+    gradient is an average over correlated samples."""
+    return int(base) * world_size(group) + rank(group)
+
+
 def shard_range(n, rank_, world):
     """Contiguous [begin, end) of n samples owned by rank_: sizes differ by at most one."""
     base, extra = divmod(n, world)

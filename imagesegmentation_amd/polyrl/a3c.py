@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import parallel
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, dynamic_rnn, glorot_uniform_
 from ..optim import FlatAdam
 from ..polyrnn import decode
@@ -128,7 +129,7 @@ class LSTMPolicy:
         self.value_kernel = torch.nn.Parameter(_dense_init((flat, 1), self.device, gen))
         self.value_bias = torch.nn.Parameter(torch.zeros([1], device=self.device))
         self._sample_calls = 0
-        self._seed = seed
+        self._seed = parallel.sampling_seed(seed)  # weights above come from `seed` itself: equal on every rank
 
     @property
     def var_list(self):

@@ -20,6 +20,7 @@ import math
 import numpy as np
 import torch
 
+from .. import parallel
 from ..convLSTM import LSTMStateTuple, RecurrentStepper, SequenceInput, _run_sequence_forward
 from ..polyrnn import decode
 from ..polyrnn.Model import Model
@@ -48,9 +49,10 @@ class ExperimentPolicyEstimator(Model):
         self.action_size = action_size
         self.tf_session = tf_session
         self.summary_writer = summary_writer
-        self._sample_seed = kwargs.pop("sample_seed", 0)
+        sample_seed = kwargs.pop("sample_seed", 0)
         self._sample_calls = 0
         super().__init__(tf_session, max_timesteps, image_size, action_size, 2, kwargs.pop("filepath", None), **kwargs)
+        self._sample_seed = parallel.sampling_seed(sample_seed, self.process_group)  # per-rank action noise
         self.gradBuffer = torch.zeros_like(self._flat_grad)
 
     # -- acting ----------------------------------------------------------------------------------
@@ -119,37 +121,62 @@ class ExperimentPolicyEstimator(Model):
         return float(loss.detach())
 
 
+class Trajectory:
+    """What one scalar episode leaves behind for the update: the image, and per step the history frames the
+    policy saw, the action it took and the reward it got."""
+
+    def __init__(self, image):
+        self.image = image
+        self.histories, self.actions, self.rewards = [], [], []
+
+    def add(self, history, action, reward):
+        self.histories.append(history)
+        self.actions.append(action)
+        self.rewards.append(reward)
+
+    @property
+    def total_reward(self):
+        return sum(self.rewards)
+
+    @property
+    def final_reward(self):
+        return self.rewards[-1] if self.rewards else 0
+
+
+def play_episode(env, policy_estimator, max_timesteps=None):
+    """Resets ``env`` and follows the policy until the episode ends or ``max_timesteps`` actions were taken."""
+    observation = env.reset()
+    trajectory = Trajectory(observation[:, :, :3])
+    rnn_state = policy_estimator.get_rnn_zero_state(batch_size=1)
+    budget = itertools.count() if max_timesteps is None else range(max_timesteps)
+    for _ in budget:
+        frames = observation[:, :, 3:]
+        action, rnn_state = policy_estimator.predict(image=trajectory.image, history=frames, rnn_state=rnn_state)
+        observation, reward, done = env.step(action)
+        trajectory.add(frames, action, reward)
+        if done:
+            break
+    return trajectory
+
+
 def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_per_episode=None, summary_writer=None,
               validate_every=None):
-    """The reference's scalar episode loop (polyrl/ReinforceOverfitExperiment.py:279-331).
+    """The reference's scalar training loop (polyrl/ReinforceOverfitExperiment.py:279-331): episode after
+    episode; an episode whose last step earned a reward (:306) adds its policy gradient, with discounted
+    returns as weights, to the estimator's buffer; the buffer is applied on every fifth episode but the
+    first (:312).  ``sess``, ``summary_writer`` and ``validate_every`` are accepted for the call shape only.
     Returns the list of episode rewards."""
-    total_reward = []
-    episodes = range(total_episodes) if total_episodes is not None else itertools.count()
-    for episode_num in episodes:
-        state = env.reset()
-        image = state[:, :, :3]
-        ep_history = []
-        total_episode_reward = 0
-        rnn_state = policy_estimator.get_rnn_zero_state(batch_size=1)
-        steps = range(max_timesteps_per_episode) if max_timesteps_per_episode is not None else itertools.count()
-        reward = 0
-        for timestep in steps:
-            histories = state[:, :, 3:]
-            action, next_rnn_state = policy_estimator.predict(image=image, history=histories, rnn_state=rnn_state)
-            next_state, reward, done = env.step(action)
-            total_episode_reward += reward
-            ep_history.append([state, action, reward, next_state, done, rnn_state])
-            state = next_state
-            rnn_state = next_rnn_state
-            if done:
-                break
-        if reward > 0:  # update only when the episode saw any reward (reference :306)
-            rewards = discount_rewards([e[2] for e in ep_history])
-            h = np.stack([e[0][:, :, 3:] for e in ep_history], axis=0)
-            policy_estimator.update(images=image, histories=h, actions=np.vstack([e[1] for e in ep_history]),
-                                    td_targets=rewards, apply_grads=episode_num % 5 == 0 and episode_num != 0)
-        total_reward.append(total_episode_reward)
-    return total_reward
+    episode_rewards = []
+    numbering = itertools.count() if total_episodes is None else range(total_episodes)
+    for episode in numbering:
+        trajectory = play_episode(env, policy_estimator, max_timesteps_per_episode)
+        if trajectory.final_reward > 0:
+            policy_estimator.update(images=trajectory.image, histories=np.stack(trajectory.histories, axis=0),
+                                    actions=np.vstack(trajectory.actions),
+                                    td_targets=discount_rewards(trajectory.rewards),
+                                    apply_grads=episode > 0 and episode % 5 == 0)
+        episode_rewards.append(trajectory.total_reward)
+    return episode_rewards
 
 
 class BatchedReinforce:

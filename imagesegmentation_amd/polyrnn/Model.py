@@ -183,6 +183,10 @@ class Model:
         self.learning_rate = learning_rate
         self.process_group = process_group
         self.global_step = 0
+        #: Adam's own step count (TensorFlow's beta1_power / beta2_power).  Not the same thing as global_step:
+        #: the reference's Saver holds the trainable variables and global_step only (polyrnn/Model.py:132-136), so
+        #: after a restore the moments and the bias correction start afresh while global_step continues.
+        self._adam_t = 0
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
         self._named = {}
@@ -310,9 +314,12 @@ class Model:
     def forward(self, images, durations, histories, initial_state=None):
         features = self.encode(images)
         seq = self._sequence_input(features, histories)
+        # durations already on the device (a batch from data.DeviceBatchBuilder) are not fetched back: all
+        # max_timesteps steps run under the per-sample mask
+        steps = self.max_timesteps if torch.is_tensor(durations) and durations.is_cuda else None
         # the head's average pool rides inside the recurrence node: its gradient is never materialised
         rnn_out, final = dynamic_rnn(self.rnn, seq, sequence_length=durations, initial_state=initial_state,
-                                     time_major=False, output_pool=self.prediction_size // self.head_size)
+                                     time_major=False, output_pool=self.prediction_size // self.head_size, steps=steps)
         self.rnn_final_state = final
         self.prediction_logits = self.head(rnn_out)
         return self.prediction_logits, final
@@ -343,8 +350,9 @@ class Model:
             self._early_reduce.finish(average=average)
         norm = flat.norm()
         self.global_step += 1
+        self._adam_t += 1
         # tf.clip_by_global_norm(grads, 1.0) (scale = clip / max(norm, clip)) is applied inside the update
-        adam_tf_step_(self._flat_param, self._adam_m, self._adam_v, flat, self.global_step, self.learning_rate,
+        adam_tf_step_(self._flat_param, self._adam_m, self._adam_v, flat, self._adam_t, self.learning_rate,
                       clip_norm=1.0 if clip else None, norm=norm)
         return norm
 
@@ -394,12 +402,22 @@ class Model:
         return sd
 
     def load_state_dict(self, sd):
+        """Variables and global_step, as the reference's Saver restores them; the optimiser's slots are not part
+        of its checkpoints, so the moments and Adam's step count restart from zero exactly as a restored
+        TensorFlow graph's do."""
         with torch.no_grad():
             for name, p in self._named_parameters():
                 p.copy_(sd[name].to(self.device))
+            self._adam_m.zero_()
+            self._adam_v.zero_()
+        self._adam_t = 0
         self.global_step = int(sd["global_step"])
+        ops.note_weights_changed()
 
     def save(self):
+        """tf.train.Saver(max_to_keep=2).save(sess, filepath + 'model', global_step) (reference
+        polyrnn/Model.py:132-148): one file per call named by the step, a `checkpoint` marker naming the
+        newest, older files beyond two removed."""
         os.makedirs(self._filepath, exist_ok=True)
         path = os.path.join(self._filepath, 'model-%d.pt' % self.global_step)
         torch.save(self.state_dict(), path)
@@ -428,74 +446,70 @@ class Model:
     #: History0Experiment builds the predicted polygon from the predictions alone (its :158)
     iou_prepend_history = True
 
-    def _stop_test(self, predicted, true_vertices, b):
-        """Close-on-first-vertex rule of the base class (Model.py:240)."""
-        return bool(np.all(predicted == true_vertices[b][-self.history_length]))
-
-    def decode(self, images, true_vertices):
-        """The reference's per-vertex loop: one recurrence step per iteration with the previous
-        state fed back, argmax decode, history shifted by np.roll(+1).  Returns
-        (predicted_vertices [B,T,2] float64, prediction_durations [B])."""
-        B = images.shape[0] if hasattr(images, "shape") else len(images)
-        T, P, hist = self.max_timesteps, self.prediction_size, self.history_length
-        predicted_vertices = np.empty([B, T, 2])
+    def _decode_on_device(self, images, true_vertices):
+        """The reference's per-vertex loop (polyrnn/Model.py:218-249) with everything between two recurrence
+        steps on the device: one fused cell launch per layer, the head GEMM and ONE isg_decode_step launch
+        (argmax, stop rule / end-token rule, predicted polygon, history roll) per vertex - no host round trip
+        inside the loop.  Returns int32 device tensors (predicted [B,T,2], durations [B], first history
+        points [B,hist,2], true polygons [B,vmax,2], their vertex counts [B])."""
+        B = len(true_vertices)
+        T, hist, dev = self.max_timesteps, self.history_length, self.device
+        vt_host, nvt_host = util.pack_polygons([np.asarray(v) for v in true_vertices])
+        vt = ops.upload(vt_host, dev, torch.int32)
+        nvt = ops.upload(nvt_host, dev, torch.int32)
         with torch.no_grad():
             features = self.encode(images)
+            n = nvt.long()[:, None]
             # frame i of the first step shows true_vertices[len - hist + i] (create_history with
-            # end_idx = len(v) - 1, Model.py:224-226)
-            pts = np.full([B, 1, max(hist, 1), 2], -1, np.int32)[:, :, :hist]
-            for b, v in enumerate(true_vertices):
-                n = len(v)
-                for i in range(hist):
-                    pts[b, 0, i] = v[(n - 1 - hist + i + 1) % n]
+            # end_idx = len(v) - 1, Model.py:224-226); the closing vertex is true_vertices[-hist] (Model.py:240)
+            first = (n - hist + torch.arange(max(hist, 1), device=dev)[None, :]) % n
+            picked = vt.gather(1, first[:, :, None].expand(-1, -1, 2))
+            close = picked[:, 0].contiguous()
+            pts0 = picked[:, :hist].contiguous()
+            pts = pts0.clone()
+            required = torch.ones([B], dtype=torch.int32, device=dev)
+            durations = torch.zeros([B], dtype=torch.int32, device=dev)
+            predicted = torch.zeros([B, T, 2], dtype=torch.int32, device=dev)
             stepper = RecurrentStepper(self.rnn, features, hist)
-            required = np.ones([B], dtype=np.uint32)
-            durations = np.zeros([B], dtype=np.uint32)
             for i in range(T):
-                dur_dev = torch.as_tensor(required.astype(np.int32), device=self.device)
-                out = stepper.step(torch.as_tensor(pts[:, 0], device=self.device), durations=dur_dev, t=0)
-                logits = self.head(out)
-                xy = decode.prediction_max(logits, self.head_size)[:, 0].cpu().numpy()
-                predicted_vertices[:, i, :] = xy
-                durations += required
-                frame = xy.copy()
-                for b in range(B):
-                    frame[b] = self._update_after_prediction(predicted_vertices, frame[b], true_vertices, b, i,
-                                                             required)
-                if hist > 0:
-                    pts = np.roll(pts, 1, axis=2)
-                    pts[:, 0, -1] = frame
+                out = stepper.step(pts, durations=required, t=0)
+                decode.decode_step(self.head(out)[:, 0], self.head_size, self.end_token, close, required, durations,
+                                   predicted, i, pts)
         self.rnn_final_state = stepper.state
-        return predicted_vertices, durations
+        #: device launches per decoded vertex: the cells, the head GEMM, the decode step
+        self.decode_launches_per_step = len(self.rnn.cells) + 2
+        return predicted, durations, pts0, vt, nvt
 
-    def _update_after_prediction(self, predicted_vertices, xy, true_vertices, b, i, required):
-        """Stop rule of the base class (Model.py:239-249): returns the point shown in the next
-        history frame."""
-        if self._stop_test(predicted_vertices[b, i, :], true_vertices, b):
-            required[b] = 0
-        return xy
+    def decode(self, images, true_vertices):
+        """Autoregressive decode: one recurrence step per vertex with the previous state fed back, argmax
+        vertex, history shifted by np.roll(+1).  Returns (predicted_vertices [B,T,2] float64,
+        prediction_durations [B]) on the host - one device-to-host copy, after the loop."""
+        predicted, durations, _, _, _ = self._decode_on_device(images, true_vertices)
+        B = predicted.shape[0]
+        both = torch.cat([predicted.reshape(B, -1), durations[:, None]], dim=1).cpu().numpy()
+        return both[:, :-1].reshape(B, -1, 2).astype(np.float64), both[:, -1].astype(np.uint32)
 
     def validate_iou(self, images, true_vertices, summary_prefix='valid', additional_feed_args={}):
-        predicted_vertices, durations = self.decode(images, true_vertices)
+        """Decode, then mask IoU of every predicted polygon against its true one (reference Model.py:208-260):
+        polygons are assembled and rasterised on the device; predictions, durations and the IoU counts come
+        back in one copy."""
+        predicted, durations, pts0, vt, nvt = self._decode_on_device(images, true_vertices)
+        B, T = predicted.shape[0], self.max_timesteps
         P, hist = self.prediction_size, self.history_length
-        scale = P // self.head_size
-        pred_polys = []
-        for b in range(len(true_vertices)):
-            pv = predicted_vertices[b][:durations[b]] if self.iou_slice_by_duration else predicted_vertices[b]
-            pv = pv * scale
-            if self.iou_prepend_history and hist > 0:
-                pv = np.concatenate([np.asarray(true_vertices[b])[-hist:], pv], axis=0)
-            pred_polys.append(pv.astype(np.int64))
-        vmax = max(max(len(p) for p in pred_polys), max(len(v) for v in true_vertices), util.VMAX_DEFAULT)
-        vp, nvp = util.pack_polygons(pred_polys, vmax=vmax)
-        vt, nvt = util.pack_polygons([np.asarray(v) for v in true_vertices], vmax=vmax)
-        dev = self.device
-        inter, union = util.raster_iou(torch.from_numpy(vp).to(dev), torch.from_numpy(nvp).to(dev),
-                                       torch.from_numpy(vt).to(dev), torch.from_numpy(nvt).to(dev), P)
-        ious = (inter.double() / union.double()).cpu().numpy()
+        count = durations if self.iou_slice_by_duration else torch.full_like(durations, T)
+        vp = predicted * (P // self.head_size)
+        if self.iou_prepend_history and hist > 0:  # the polygon starts with the last `hist` true vertices
+            vp = torch.cat([pts0, vp], dim=1)
+            count = count + hist
+        vmax = max(vp.shape[1], vt.shape[1], util.VMAX_DEFAULT)
+        pad = lambda v: torch.nn.functional.pad(v, (0, 0, 0, vmax - v.shape[1])).contiguous()
+        inter, union = util.raster_iou(pad(vp), count.contiguous(), pad(vt), nvt, P)
+        back = torch.cat([predicted.reshape(B, -1), durations[:, None], inter[:, None], union[:, None]], dim=1)
+        back = back.cpu().numpy()
+        ious = back[:, -2].astype(np.float64) / back[:, -1].astype(np.float64)
         self.last_ious = ious
-        self.last_predicted_vertices = predicted_vertices
-        self.last_prediction_durations = durations
+        self.last_predicted_vertices = back[:, :-3].reshape(B, T, 2).astype(np.float64)
+        self.last_prediction_durations = back[:, -3].astype(np.uint32)
         tag = summary_prefix + '/iou' if summary_prefix else 'iou'
         self._add_summaries(summary_prefix or 'valid', extra={tag: float(np.mean(ious))})
         return float(np.mean(ious))

@@ -107,3 +107,18 @@ def sample_actions(logits, seed, grid_side, row_offset=0, row_offset_dev=None, o
                                        _lib.ptr(row_offset_dev), int(grid_side), _lib.ptr(out), _lib.current_stream())
     _lib.check(rc, "isg_sample_actions")
     return out
+
+
+def decode_step(logits, grid_side, end_token, close_xy, required, durations, predicted, step, history_points):
+    """isg_decode_step: argmax of every row, then the decode loop's bookkeeping (stop rule, predicted polygon,
+    history points of the next step) on the device.  logits [B, K]; all other tensors int32 and updated in
+    place: close_xy [B,2], required [B], durations [B], predicted [B,T,2], history_points [B,hist,2]."""
+    z, rows, cols = _rows(logits)
+    hist = history_points.shape[1]
+    for t in (close_xy, required, durations, predicted, history_points):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    rc = _lib.lib().isg_decode_step(_lib.ptr(z), rows, cols, dtype_code(z.dtype), int(grid_side), int(bool(end_token)),
+                                    _lib.ptr(close_xy), _lib.ptr(required), _lib.ptr(durations), _lib.ptr(predicted),
+                                    predicted.shape[1], int(step), _lib.ptr(history_points) if hist else None, hist,
+                                    _lib.current_stream())
+    _lib.check(rc, "isg_decode_step")

@@ -13,8 +13,6 @@ decode / IoU variant.  ``make(name, ...)`` builds one with the reference's hyper
  EndToken           EndTokenExperiment.py:20-58,200-203        16@5,16@5,16@3          2   10   2   P^2+1
  EndTokenDeep_2     EndTokenDeepExperiment_2.py:19-57,202-205  16@5,16@5,5x16@3        2   10   5   P^2+1
 """
-import numpy as np
-
 from .Model import Model
 
 
@@ -50,13 +48,6 @@ class EndToken(History2Large):
     vertex in the predicted polygon and by point (0, 0) in the next history frame
     (reference polyrnn/EndTokenExperiment.py:158-170)."""
     end_token = True
-
-    def _update_after_prediction(self, predicted_vertices, xy, true_vertices, b, i, required):
-        if np.all(predicted_vertices[b, i, :] == np.array([self.head_size, 0])):
-            required[b] = 0
-            predicted_vertices[b, i, :] = true_vertices[b][-self.history_length]
-            xy = np.zeros_like(xy)
-        return xy
 
 
 class EndTokenDeep_2(EndToken):

@@ -78,6 +78,22 @@ int isg_shape_mask(const int32_t* verts, const int32_t* nverts, int n, int vmax,
 int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out, int out_channels,
                        int out_offset, void* stream);
 
+/* The teacher-forcing batch builder (reference Dataset.py:104-150 get_batch_for_rnn / _create_sample_sequence,
+ * EndTokenDataset.py:132-152) for B samples in one launch, from a dataset kept on the device as a padded
+ * vertex table.  The reference's random draws (which samples, which start vertex) are the caller's: `indices`
+ * and `starts`.  Sample b = polygon indices[b] rolled by starts[b] as np.roll does (rolled vertex k is vertex
+ * (k - start) mod n).  With n its vertex count:
+ *   durations[b] = n - hist + 1;  steps t < min(durations[b], T) are filled:
+ *   points [B][T][hist][2]: frame i of step t = rolled vertex t - hist + i + 1 (the reference's create_history
+ *                           with end_idx = t), as (x, y); (-1, -1) for steps that are not filled;
+ *   targets [B][T][2]:      rolled vertex t + 1; (0, 0) for steps that are not filled; with end_token the
+ *                           target of the last filled step is (P, 0) (EndTokenDataset.py:150);
+ *   rolled [B][vcap][2] (may be NULL): the rolled polygon, zeros past n;  nverts [B] (may be NULL): n.
+ * table int32 [N][vcap][2], counts int32 [N] (each 1..vcap), indices / starts int32 [B]. */
+int isg_batch_points(const int32_t* table, const int32_t* counts, int vcap, const int32_t* indices,
+                     const int32_t* starts, int B, int T, int hist, int P, int end_token, int32_t* durations,
+                     int32_t* points, int32_t* targets, int32_t* rolled, int32_t* nverts, void* stream);
+
 /* One step of n lock-stepped polygon environments, everything but the reward (reference
  * polyrl/polygon_env.py:25-46 and polyrl/polygon_env_end_token.py:25-47 for one environment):
  * an environment that is not done appends the action to its predicted polygon (the end token
@@ -223,6 +239,22 @@ int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned 
 int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
                        unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
                        int32_t* out_xy, void* stream);
+
+/* One iteration of the reference's autoregressive decode loop (polyrnn/Model.py:231-249; end-token variant
+ * polyrnn/EndTokenExperiment.py:158-170, EndTokenDeepExperiment_2.py:150-170) for every sample, in one launch
+ * after the head, with no host round trip.  Per row r of logits [rows][cols]:
+ *   class = argmax (first maximum);  (x, y) = (class / P, class % P)  - the end token class P*P is (P, 0);
+ *   durations[r] += required[r]                              (steps the sample was still decoding);
+ *   without end token: (x, y) == close_xy[r] clears required[r]   (Model.py:239-242: the closing vertex);
+ *   with end token:    (x, y) == (P, 0) clears required[r], the predicted vertex becomes close_xy[r] and the
+ *                      next history frame shows (0, 0);
+ *   predicted[r][step] = the vertex;  history_points[r] rolls by one frame (the last wraps to the front) and
+ *   its last frame becomes the vertex's point (Model.py:244-249: np.roll(+1), newest frame overwritten).
+ * required int32 [rows] is what the next step's recurrence takes as sequence lengths (1 = still decoding).
+ * predicted int32 [rows][T][2], history_points int32 [rows][hist][2], close_xy int32 [rows][2]. */
+int isg_decode_step(const void* logits, int rows, int cols, int dtype, int P, int end_token, const int32_t* close_xy,
+                    int32_t* required, int32_t* durations, int32_t* predicted, int T, int step,
+                    int32_t* history_points, int hist, void* stream);
 
 /* Masked metrics of reference polyrnn/Model.py:44-54 in one launch: pred int32 [B*T] (argmax class),
  * targets int32 [B][T][2] (x, y), durations int32 [B], P = side of the class grid (class = x*P + y;

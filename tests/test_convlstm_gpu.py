@@ -144,6 +144,39 @@ def test_dynamic_rnn_forward_backward_with_sequence_lengths(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dynamic_rnn_without_grad_keeps_nothing_and_matches(dtype):
+    """Under no_grad (validation, decode) the recurrence runs on two alternating state buffers and writes no
+    gate tensors; outputs and final states are bit-identical to the differentiable path's."""
+    from imagesegmentation_amd import convLSTM
+    from imagesegmentation_amd.convLSTM import dynamic_rnn
+    rs = np.random.RandomState(12)
+    T, B, H, W, C, L = 5, 4, 28, 28, 18, 2
+    _, multi = _stack(rs, C, L, dtype, (H, W))
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    x = t(rs.randn(T, B, H, W, C), dtype)
+    durations = np.array([5, 0, 3, 1], np.int32)
+    init = tuple((t(rs.randn(B, H, W, 16) * 0.3), t(rs.randn(B, H, W, 16) * 0.3, dtype)) for _ in range(L))
+    out_g, fin_g = dynamic_rnn(multi, x, sequence_length=durations, initial_state=init)  # weights require grad
+    assert out_g.grad_fn is not None
+    calls = []
+    real = convLSTM._run_sequence_forward
+    convLSTM._run_sequence_forward = lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            out_n, fin_n = dynamic_rnn(multi, x, sequence_length=durations, initial_state=init)
+            out_0, fin_0 = dynamic_rnn(multi, x, sequence_length=np.zeros([B], np.int32), initial_state=init)
+    finally:
+        convLSTM._run_sequence_forward = real
+    assert calls == [False, False]  # save=False: no gate tensors, no per-step state copies
+    assert out_n.grad_fn is None and torch.equal(out_n, out_g.detach())
+    for l in range(L):
+        assert torch.equal(fin_n[l].c, fin_g[l].c.detach()) and torch.equal(fin_n[l].h, fin_g[l].h.detach())
+        # no step ran: the state comes back as a copy of the initial one, never the caller's own tensor
+        assert torch.equal(fin_0[l].c, init[l][0]) and fin_0[l].c.data_ptr() != init[l][0].data_ptr()
+    assert float(out_0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("dense", [True, False])
 def test_tiled_features_plus_history_input(dtype, dense):
     """The reference's tile(conv3) ++ history input without materialising the tiled tensor."""

@@ -38,6 +38,39 @@ def test_xent_forward_backward_and_argmax(rows, cols, dtype):
     assert np.array_equal(pm.cpu().numpy(), oc.prediction_max(zr, 28))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_masked_logits_stay_finite(dtype):
+    """-inf entries (masked classes) take no part: loss, gradient and argmax stay finite wherever a lane's first
+    column is -inf, and a row of nothing but -inf reports its first column instead of an out-of-range index."""
+    from imagesegmentation_amd.polyrnn import decode
+    rs = np.random.RandomState(5)
+    rows, cols = 6, 200
+    z = rs.randn(rows, cols) * 2
+    z[0, :64] = -np.inf          # every lane's first column masked
+    z[1, ::2] = -np.inf
+    z[2, :] = -np.inf
+    z[2, 137] = 1.5              # a single live class
+    z[3, :] = -np.inf            # nothing live at all
+    labels = np.array([100, 1, 137, 0, 5, 7])
+    tz = torch.tensor(z, dtype=dtype, device=DEV).requires_grad_(True)
+    zr = tz.detach().double().cpu().numpy()
+    loss_rows = decode.softmax_xent_rows(tz, torch.tensor(labels, device=DEV), None)
+    got = loss_rows.detach().cpu().numpy()
+    live = [0, 1, 2, 4, 5]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = zr[live].max(axis=1, keepdims=True)
+        ref = (m[:, 0] + np.log(np.exp(zr[live] - m).sum(axis=1))) - zr[live, labels[live]]
+    assert np.all(np.isfinite(got[live])) and np.allclose(got[live], ref, rtol=2e-5, atol=2e-5)
+    assert abs(got[2]) < 1e-6    # the only live class is the label: loss 0
+    am = decode.argmax_rows(tz.detach()).cpu().numpy()
+    assert np.array_equal(am[live], np.argmax(zr[live], axis=1)) and am[3] == 0
+    a = decode.sample_rows(tz.detach(), seed=9).cpu().numpy()
+    assert a[2] == 137 and 0 <= a[3] < cols and np.all(np.isfinite(zr[live, a[live]]))
+    loss_rows[live].sum().backward()
+    g = tz.grad.double().cpu().numpy()
+    assert np.all(np.isfinite(g[live])) and np.all(g[0, :64] == 0) and np.all(g[1, ::2] == 0)
+
+
 def test_sampling_follows_softmax():
     from imagesegmentation_amd.polyrnn import decode
     rs = np.random.RandomState(0)
@@ -240,3 +273,39 @@ def test_rollout_from_device_pool_matches_host_reset(end_token):
     for key in ("actions", "lengths", "reward", "inter", "union", "done", "points"):
         assert torch.equal(eps[0][key], eps[1][key]), key
     assert int(eps[0]["done"].sum()) > 0
+
+
+def test_scalar_reinforce_loop_schedule():
+    """reinforce() (reference polyrl/ReinforceOverfitExperiment.py:279-331) on the drop-in scalar environment: an
+    episode is learnt from only when its last step earned a reward, with discounted returns as weights, and
+    the gradient buffer is applied on every fifth episode but the first."""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl.polygon_env_end_token import PolygonEnv
+    from imagesegmentation_amd.polyrl.reinforce import ExperimentPolicyEstimator, discount_rewards, reinforce
+    P, T = 28, 10
+    ds = data.PolygonDataset.synthetic(4, P, P, T, 2, seed=6, shape_mask_fn=oracle_raster.create_shape_mask)
+    pol = ExperimentPolicyEstimator(P, P, max_timesteps=T, end_token=True, device=DEV, sample_seed=3)
+    with torch.no_grad():
+        pol.dense_bias[-1] += 6.0   # the end token comes early and often
+    calls = []
+    real_update = pol.update
+
+    def spy(images, histories, actions, td_targets, apply_grads):
+        calls.append(dict(n=len(actions), td=np.asarray(td_targets), apply=apply_grads, actions=np.asarray(actions),
+                          frames=np.asarray(histories)))
+        return real_update(images, histories, actions, td_targets, apply_grads)
+
+    pol.update = spy
+    np.random.seed(2)
+    env = PolygonEnv(ds)
+    rewards = reinforce(env, None, pol, total_episodes=11, max_timesteps_per_episode=T)
+    assert len(rewards) == 11 and all(0.0 <= r <= 1.0 for r in rewards)
+    earning = [k for k, r in enumerate(rewards) if r > 0]
+    assert len(calls) == len(earning) and len(earning) >= 3
+    for k, c in zip(earning, calls):
+        assert c["apply"] == (k in (5, 10))
+        assert c["actions"][-1].tolist() == [P, 0] and c["frames"].shape == (c["n"], P, P, 2)
+        # the only reward is the terminal IoU: returns are its discounted tail
+        assert np.allclose(c["td"], discount_rewards([0.0] * (c["n"] - 1) + [rewards[k]]))
+    applied = sum(1 for k in earning if k in (5, 10))
+    assert pol.global_step == applied

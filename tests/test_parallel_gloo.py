@@ -115,6 +115,7 @@ def _worker(rank, world, port, ret):
         out[mode] = flat.numpy()
     out["early"] = _early_tail_case(rank)
     out["max"] = parallel.allreduce_max(float(rank + 1), "cpu")
+    out["seeds"] = [parallel.sampling_seed(b) for b in (0, 1, 7)]
     out["adam"] = _adam_case([_rank_grads(rank)], all_reduce=True)
     ret[rank] = out
     dist.destroy_process_group()
@@ -140,12 +141,16 @@ def test_two_rank_gradients_match_single_process():
         assert np.allclose(ret[rank]["early"][0], (locals_[0][0] + locals_[1][0]) / 2, rtol=1e-6, atol=1e-6)
         assert np.allclose(ret[rank]["early"][1], locals_[0][1] + locals_[1][1], rtol=1e-6, atol=1e-6)
         assert ret[rank]["max"] == 2.0
+    # per-rank action noise: no two (base seed, rank) pairs share a sampling seed
+    assert ret[0]["seeds"] == [0, 2, 14] and ret[1]["seeds"] == [1, 3, 15]
+    for rank in (0, 1):
         assert np.allclose(ret[rank]["adam"], _adam_case([_rank_grads(0), _rank_grads(1)], all_reduce=False),
                            rtol=1e-6, atol=1e-7)
 
 
 def test_shard_range_partitions_exactly():
     from imagesegmentation_amd import parallel
+    assert [parallel.sampling_seed(b) for b in (0, 5)] == [0, 5]  # one process: the seed itself
     for n in (0, 1, 7, 64, 16384, 16385):
         for world in (1, 2, 3, 8):
             spans = [parallel.shard_range(n, r, world) for r in range(world)]
