@@ -463,6 +463,11 @@ class _SequenceFunction(torch.autograd.Function):
         seq._buf_t = None
         # per-workgroup weight-gradient sums stay in a private workspace over the whole sweep
         slabs = [ops.wgrad_workspace(packed[l].cs, F, dev, cached=False) for l in range(L)]
+        # One launch per (step, layer) where the fused backward kernel exists (bf16): it reads the incoming state
+        # gradients of neighbouring tiles' border pixels, so they alternate between two buffers per layer.
+        fused = [ops.bwd_fused_supported(packed[l], B, H, W) for l in range(L)]
+        dc_next = [torch.empty_like(dc_state[l]) if fused[l] else None for l in range(L)]
+        dh_next = [torch.empty_like(dh_state[l]) if fused[l] else None for l in range(L)]
         for t in reversed(range(t_run)):
             x0 = seq.get(t)
             for l in reversed(range(L)):
@@ -472,21 +477,28 @@ class _SequenceFunction(torch.autograd.Function):
                     above, stride, k = d_out[:, t], T * (H // pool) * (W // pool) * F, pool
                 else:
                     above, stride, k = dx_mid, H * W * F, 1
+                mode = ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST
+                if l > 0:
+                    dx_args = dict(dx=dx_mid, dx_channels=F)
+                elif seq.x_seq is not None:
+                    dx_args = dict(dx=d_in[t], dx_channels=dx0_channels)
+                elif dx0_channels % 4 == 0:
+                    dx_args = dict(dx=d_in, dx_channels=dx0_channels, dx_accumulate=t < t_run - 1)
+                else:
+                    raise NotImplementedError("static feature channels must be a multiple of 4")
+                pts = seq.points(t) if l == 0 else None
+                if fused[l]:
+                    ops.bwd_fused(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l], x_in,
+                                  Hs[l][t], packed[l], dc_next[l], dh_next[l], slabs[l], mode, grads[l][0],
+                                  durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
+                    dc_state[l], dc_next[l] = dc_next[l], dc_state[l]
+                    dh_state[l], dh_next[l] = dh_next[l], dh_state[l]
+                    continue
                 ops.pointwise_bwd(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l],
                                   durations_dev, t, dy=dy, dc_prev=dc_state[l], pool=k)
                 ops.wgrad(x_in, Hs[l][t], dy, packed[l].c, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t,
-                          hist_points=seq.points(t) if l == 0 else None, hist=packed[l].hist,
-                          mode=ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST, workspace=slabs[l])
-                if l > 0:
-                    ops.dgrad(dy, packed[l], dh_state[l], dx=dx_mid, dx_channels=F, durations=durations_dev, t=t)
-                elif seq.x_seq is not None:
-                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in[t], dx_channels=dx0_channels,
-                              durations=durations_dev, t=t)
-                elif dx0_channels % 4 == 0:
-                    ops.dgrad(dy, packed[0], dh_state[0], dx=d_in, dx_channels=dx0_channels,
-                              dx_accumulate=t < t_run - 1, durations=durations_dev, t=t)
-                else:
-                    raise NotImplementedError("static feature channels must be a multiple of 4")
+                          hist_points=pts, hist=packed[l].hist, mode=mode, workspace=slabs[l])
+                ops.dgrad(dy, packed[l], dh_state[l], durations=durations_dev, t=t, **dx_args)
         if t_run > 0:
             for l in range(L):
                 ops.wgrad_finish(slabs[l], (B, H, W, packed[l].cs), packed[l].c, packed[l].hist, *grads[l])

@@ -1,0 +1,597 @@
+// One backward step of the ConvLSTM cell in ONE kernel (bf16): gate backward + data gradient + weight gradient.
+//
+// The three-kernel backward (pointwise -> dY in HBM -> data gradient and weight gradient each reading dY back)
+// moves dY three times: 384 of its ~1,000 bytes per pixel.  Here the pre-activation gradient dY exists only in
+// LDS.  Per 8 x 32 (or 4 x 32) pixel tile a 512-thread workgroup
+//   A. computes dY for the tile AND its one-pixel halo from the saved gate activations, cell states and the
+//      incoming gradients (the halo pixels' values are recomputed by the neighbouring tiles, bit for bit the
+//      same), writes it to LDS twice - a padded pixel-major halo image for the data gradient's B operand and an
+//      unpadded interior image in 64-byte regions for the weight gradient's transposing reads - stores dc_prev
+//      for the tile's own pixels, and stages the [x | h_prev] halo tile beside it;
+//   B. runs the data gradient (each wave one tile row x one 32-row tile of input channels, weight image resident
+//      in LDS) and stores dx / dh_prev, then the weight gradient (each wave a group of taps x one 32-column half
+//      of dY; the accumulators stay in registers over all tiles and leave as one slab per workgroup).
+// The next tile's operands are requested pass by pass as phase A frees the registers that held this tile's, so
+// loads are in flight through the whole of phase B: the kernel is HBM-bound (about 650 - 900 bytes per pixel
+// against ~150 MFMA per tile per SIMD).
+#include <utility>
+
+#include "isg_convlstm_shared.h"
+
+using namespace isgc;
+
+namespace {
+
+constexpr int kBwdThreads = 512;
+
+struct BwdParams {
+    const void* gates;      // [B,H,W,F,4] post-activation (tanh j, sig i, sig f, sig o)
+    const float* c_prev;    // [B,H,W,F]
+    const float* c_cur;     // [B,H,W,F]
+    const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
+    long long dh_above_bstride;
+    int pool_shift;         // > 0: dh_above lives on the grid pooled by 2^s x 2^s windows (average pool)
+    const void* dh_state;   // [B,H,W,F]
+    const void* dc_state;   // [B,H,W,F] bf16
+    const void* x;          // [B,H,W,C0]
+    const void* h_prev;     // [B,H,W,F]
+    int B, H, W, tiles_x, tiles_y;
+    const int* durations;
+    int t;
+    const void* wimg;       // data-gradient weight image, row-tile-major
+    void* dc_prev;          // [B,H,W,F] bf16, NOT the dc_state buffer (halo pixels are read by neighbouring tiles)
+    void* dh_prev;          // [B,H,W,F], NOT the dh_state buffer
+    void* dx;               // [B,H,W,dx_cstride] or null
+    int dx_channels, dx_cstride, dx_accumulate;
+    float* slab;            // [grid][9][MT*32][64]
+    float* bias_slab;       // [grid][64]
+    int slab_accumulate;
+    const int* hist_points; // [B][hist][2] of this step, sample stride hist_bstride ints
+    int hist;
+    long long hist_bstride;
+    void* hist_dy;          // [B][hist][9][64] bf16, zeroed by the host: dY at the pixel each tap reaches from a point
+};
+
+template <int C0, int MT, int TR>
+struct FB {
+    static constexpr int NPXH = (TR + 2) * HALO_W;       // halo tile pixels
+    static constexpr int DY_PSTRIDE = NG * 2 + 16;       // padded pixel stride of the halo dY image
+    static constexpr int DYH_BYTES = NPXH * DY_PSTRIDE;
+    static constexpr int RSTRIDE = 64;                   // 32 channels: one region row
+    static constexpr int DYI_REGION = TR * TW * RSTRIDE + 128;
+    static constexpr int DYI_BYTES = 2 * DYI_REGION;
+    static constexpr int IN_REGION = NPXH * RSTRIDE;
+    static constexpr int IN_BYTES = MT * IN_REGION;
+    static constexpr int NS = 9 * (NG / 16);             // k-steps of the data gradient
+    static constexpr int W_BYTES = NS * MT * 1024;
+    static constexpr int OFF_DYH = W_BYTES, OFF_DYI = OFF_DYH + DYH_BYTES, OFF_IN = OFF_DYI + DYI_BYTES;
+    static constexpr int LDS_BYTES = OFF_IN + IN_BYTES;
+    static constexpr int NPW = (NPXH * 8 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (16 B of gates each)
+    static constexpr int NCH0 = C0 / 8, NCHT = NCH0 + 2;                    // 16-byte chunks of x / of [x | h_prev]
+    static constexpr int NXP = (NPXH * NCHT + kBwdThreads - 1) / kBwdThreads;
+    static constexpr int NSLOT = MT == 1 ? 3 : 5;        // (tap, row tile) pairs per wave in the weight gradient
+    static_assert(TR * MT == 8, "one data-gradient unit (tile row x row tile) per wave");
+    static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0 && C0 <= 32, "input channels must fit the row tiles");
+    static_assert(DYH_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+template <int C0, int MT, int TR>
+__global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
+    using K = FB<C0, MT, TR>;
+    using T = __bf16;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    (void)sizeof(s16x8);
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w = smem;
+    char* lds_dyh = smem + K::OFF_DYH;
+    char* lds_dyi = smem + K::OFF_DYI;
+    char* lds_in = smem + K::OFF_IN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, px_l = lane & 31;
+
+    {  // weight image, once per workgroup; channels past the real ones of the [x | h_prev] image stay zero
+        const uint4* src = static_cast<const uint4*>(p.wimg);
+        uint4* dst = reinterpret_cast<uint4*>(lds_w);
+        for (int i = tid; i < K::W_BYTES / 16; i += kBwdThreads) dst[i] = src[i];
+        if constexpr (C0 + F_ < MT * 32) {
+            for (int i = tid; i < K::IN_BYTES / 16; i += kBwdThreads)
+                reinterpret_cast<uint4*>(lds_in)[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int ntiles = tiles_per_img * p.B;
+    const int n_iter = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    // ---- where this thread's items of every pass sit in the halo tile (fixed for the whole kernel) ----
+    const int q = tid & 7;  // gate-backward item = (halo pixel, channel pair q): 512 % 8 == 0 keeps q per thread
+    int pinfo[K::NPW];      // hy | hx << 8 | exists << 31
+#pragma unroll
+    for (int j = 0; j < K::NPW; ++j) {
+        const int px = j * (kBwdThreads / 8) + (tid >> 3);
+        const bool exists = px < K::NPXH;
+        const int cpx = exists ? px : K::NPXH - 1;
+        const int hy = cpx / HALO_W, hx = cpx - hy * HALO_W;
+        pinfo[j] = hy | hx << 8 | (exists ? (int)0x80000000 : 0);
+    }
+    int xinfo[K::NXP];      // LDS byte offset (bits 0-17) | hy << 18 | hx << 22 | chunk << 28 | exists << 31
+#pragma unroll
+    for (int j = 0; j < K::NXP; ++j) {
+        const int idx = j * kBwdThreads + tid;
+        const bool exists = idx < K::NPXH * K::NCHT;
+        const int cidx = exists ? idx : K::NPXH * K::NCHT - 1;
+        const int px = cidx / K::NCHT, ch = cidx - px * K::NCHT;
+        const int hy = px / HALO_W, hx = px - hy * HALO_W;
+        const int cbyte = (ch < K::NCH0 ? ch * 8 : C0 + (ch - K::NCH0) * 8) * 2;  // byte in the [x | h_prev] row
+        const int ldso = (cbyte / K::RSTRIDE) * K::IN_REGION + px * K::RSTRIDE + (cbyte % K::RSTRIDE);
+        xinfo[j] = ldso | hy << 18 | hx << 22 | ch << 28 | (exists ? (int)0x80000000 : 0);
+    }
+    static_assert(K::IN_BYTES < (1 << 18), "LDS offsets are packed into 18 bits");
+
+    // ---- staged operands of one tile ----
+    uint4 sg[K::NPW];              // gates: 2 channels x 4 gates
+    uint2 scp[K::NPW], scc[K::NPW];  // c_prev, c_cur: 2 floats
+    unsigned sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 2 bf16
+    uint4 sx[K::NXP];
+    unsigned pw_inside = 0u, x_inside = 0u;
+    int st_dur = 0x7fffffff;
+    int st_hp[4] = {-1, 0, -1, 0};
+
+    struct Tile {
+        int b, ty0, tx0;
+        bool valid;
+    };
+    // Every load below is issued unconditionally, from addresses clamped into the tensors (a tile past the end
+    // re-reads the last one, a missing optional tensor reads the gate tensor instead) and its value is dropped
+    // or zeroed at the use: with loads under branches the compiler can no longer count what is in flight and
+    // waits for ALL of it (s_waitcnt vmcnt(0)) at the first use, which serialises the prefetch with the math.
+    auto tile_ref = [&](int k) {
+        Tile r;
+        const int tile = k * (int)gridDim.x + (int)blockIdx.x;
+        r.valid = k < n_iter && tile < ntiles;
+        const int ctile = min(tile, ntiles - 1);
+        r.b = ctile / tiles_per_img;
+        const int rem = ctile - r.b * tiles_per_img;
+        const int tyi = rem / p.tiles_x;
+        r.ty0 = tyi * TR, r.tx0 = (rem - tyi * p.tiles_x) * TW;
+        return r;
+    };
+    const float inv_pool = 1.0f / (float)(1 << (2 * p.pool_shift));
+    const int* dur_base = p.durations != nullptr ? p.durations : reinterpret_cast<const int*>(p.gates);
+    const int dur_mul = p.durations != nullptr ? 1 : 0;
+    const int* hp_base = p.hist > 0 ? p.hist_points : reinterpret_cast<const int*>(p.gates);
+    const long long hp_bstride = p.hist > 0 ? p.hist_bstride : 0;
+    const int hp_last = p.hist > 0 ? 2 * p.hist - 1 : 0;
+
+    auto load_meta = [&](const Tile& r) {
+        pw_inside = 0u, x_inside = 0u;
+        st_dur = dur_base[r.b * dur_mul];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st_hp[i] = hp_base[(size_t)r.b * hp_bstride + min(i, hp_last)];
+    };
+    auto load_pw = [&](const Tile& r, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        // (the packed word is laundered at every use: otherwise its unpacked fields are hoisted out of the tile
+        // loop into registers of their own, a dozen of them, and the kernel spills)
+        int inf = pinfo[j];
+        asm volatile("" : "+v"(inf));
+        const int hy = inf & 0xff, hx = (inf >> 8) & 0xff;
+        const int gy = r.ty0 - 1 + hy, gx = r.tx0 - 1 + hx;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && inf < 0) pw_inside |= 1u << j;
+        const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        const unsigned pix = (unsigned)(cy * p.W + cx);
+        const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
+        sg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 16u));
+        scp[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 8u));
+        scc[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.c_cur) + (size_t)(pixel * 64u + q * 8u));
+        const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
+        sda[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
+                                                    (size_t)(apix * (unsigned)(F_ * 2) + q * 4u));
+        sds[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 4u));
+        sdc[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 4u));
+    };
+    auto load_x = [&](const Tile& r, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        int inf = xinfo[j];
+        asm volatile("" : "+v"(inf));
+        const int hy = (inf >> 18) & 15, hx = (inf >> 22) & 63, ch = (inf >> 28) & 7;
+        const int gy = r.ty0 - 1 + hy, gx = r.tx0 - 1 + hx;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && inf < 0) x_inside |= 1u << j;
+        const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        const unsigned pixel = (unsigned)((r.b * p.H + cy) * p.W + cx);
+        const bool is_h = ch >= K::NCH0;
+        const char* base = is_h ? static_cast<const char*>(p.h_prev) : static_cast<const char*>(p.x);
+        const unsigned off = is_h ? pixel * (unsigned)(F_ * 2) + (unsigned)(ch - K::NCH0) * 16u
+                                  : pixel * (unsigned)(C0 * 2) + (unsigned)ch * 16u;
+        sx[j] = *reinterpret_cast<const uint4*>(base + (size_t)off);
+    };
+
+    // ---- weight-gradient work of this wave: a group of (tap, row tile) pairs x one 32-column half of dY ----
+    const int wg_n = wave & 1, wg_grp = wave >> 1;
+    int wg_first, wg_cnt;
+    if constexpr (MT == 1) {
+        wg_first = wg_grp == 0 ? 0 : 2 * wg_grp + 1, wg_cnt = wg_grp == 0 ? 3 : 2;  // {0,1,2} {3,4} {5,6} {7,8}
+    } else {
+        wg_first = wg_grp < 2 ? 5 * wg_grp : 10 + 4 * (wg_grp - 2), wg_cnt = wg_grp < 2 ? 5 : 4;  // 5 + 5 + 4 + 4 of 18
+    }
+    const bool wg_full = wg_cnt == K::NSLOT;  // the last slot is used by the larger groups only
+    f32x16 wacc[K::NSLOT];
+#pragma unroll
+    for (int i = 0; i < K::NSLOT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[i][r] = 0.0f;
+    float bsum = 0.0f;
+    // this lane's fixed read positions in the dY interior image and, per slot, in the [x | h_prev] halo image
+    const char* wg_dy;
+    const char* wg_in[K::NSLOT];
+    {
+        const int li = lane & 15, g16 = lane >> 4;
+        const int csub = 16 * (g16 & 1) + 4 * (li & 3);      // channel offset inside the 32-channel region
+        const int lane_px = 8 * half + (li >> 2);            // pixel inside the 16-pixel k-step (second read: + 4)
+        wg_dy = lds_dyi + wg_n * K::DYI_REGION + lane_px * K::RSTRIDE + csub * 2;
+#pragma unroll
+        for (int i = 0; i < K::NSLOT; ++i) {
+            const int pair = wg_first + min(i, wg_cnt - 1);
+            const int tap = MT == 1 ? pair : pair >> 1, mt = MT == 1 ? 0 : pair & 1;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            wg_in[i] = lds_in + mt * K::IN_REGION + (dy * HALO_W + dx + lane_px) * K::RSTRIDE + csub * 2;
+        }
+    }
+
+    // data-gradient unit of this wave
+    const int dg_row = MT == 1 ? wave : wave >> 1, dg_mt = MT == 1 ? 0 : wave & 1;
+
+    Tile cur = tile_ref(0);
+    load_meta(cur);
+    [&]<int... I>(std::integer_sequence<int, I...>) { (load_pw(cur, std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, K::NPW>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(cur, std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, K::NXP>{});
+    __syncthreads();
+
+    for (int k = 0; k < n_iter; ++k) {
+        const Tile nxt = tile_ref(k + 1);
+        const bool live = cur.valid && (p.durations == nullptr || p.t < __builtin_amdgcn_readfirstlane(st_dur));
+        int hp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hp[i] = __builtin_amdgcn_readfirstlane(st_hp[i]);
+        const unsigned cur_pw_inside = pw_inside, cur_x_inside = x_inside;
+
+        // the running dx sum this wave's epilogue adds to: requested before anything of the next tile, so that
+        // waiting for it does not wait for the prefetch behind it
+        uint2 pre[4];
+        const int egy = cur.ty0 + dg_row, egx = cur.tx0 + px_l;
+        const bool e_in = cur.valid && egy < p.H && egx < p.W;
+        const size_t epixel = (size_t)(unsigned)((cur.b * p.H + min(egy, p.H - 1)) * p.W + min(egx, p.W - 1));
+        if (live && p.dx && p.dx_accumulate) {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
+                pre[a4] = make_uint2(0u, 0u);
+                if (cc0 < C0 && cc0 < p.dx_channels)
+                    pre[a4] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.dx) + epixel * p.dx_cstride + cc0);
+            }
+        }
+
+        // ---------------- phase A: dY of the halo tile into LDS, dc_prev, the [x | h_prev] image ----------------
+        load_meta(nxt);  // (after this tile's facts were taken out of the staging words above)
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int j = I;
+                int inf = pinfo[j];
+                asm volatile("" : "+v"(inf));
+                if (cur.valid && inf < 0) {
+                    const int hy = inf & 0xff, hx = (inf >> 8) & 0xff;
+                    const bool inside = (cur_pw_inside >> j) & 1u;
+                    const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
+                    const int gy = cur.ty0 - 1 + hy, gx = cur.tx0 - 1 + hx;
+                    float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const unsigned u_dc = sdc[j], u_dh = sds[j], u_da = sda[j];
+                    float dcp[2] = {bf_lo(u_dc), bf_hi(u_dc)};
+#ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
+                    if (false) {
+#else
+                    if (live && inside) {
+#endif
+                        const float gv[8] = {bf_lo(sg[j].x), bf_hi(sg[j].x), bf_lo(sg[j].y), bf_hi(sg[j].y),
+                                             bf_lo(sg[j].z), bf_hi(sg[j].z), bf_lo(sg[j].w), bf_hi(sg[j].w)};
+                        const float cpv[2] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y)};
+                        const float ccv[2] = {__uint_as_float(scc[j].x), __uint_as_float(scc[j].y)};
+                        float da[2] = {bf_lo(u_da), bf_hi(u_da)};
+                        da[0] *= inv_pool, da[1] *= inv_pool;
+                        const float dh[2] = {da[0] + bf_lo(u_dh), da[1] + bf_hi(u_dh)};
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float g = gv[4 * c], ig = gv[4 * c + 1], fg = gv[4 * c + 2], og = gv[4 * c + 3];
+                            const float tc = act_tanh<true>(ccv[c]);
+                            const float d_o = dh[c] * tc;
+                            const float dct = dcp[c] + dh[c] * og * (1.0f - tc * tc);
+                            out[4 * c] = dct * ig * (1.0f - g * g);
+                            out[4 * c + 1] = dct * g * ig * (1.0f - ig);
+                            out[4 * c + 2] = dct * cpv[c] * fg * (1.0f - fg);
+                            out[4 * c + 3] = d_o * og * (1.0f - og);
+                            dcp[c] = dct * fg;
+                        }
+                    }
+                    const bf16x8 o = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
+                    if (live) {
+                        const int px = hy * HALO_W + hx;
+                        *reinterpret_cast<bf16x8*>(lds_dyh + px * K::DY_PSTRIDE + q * 16) = o;
+                        if (own)
+                            *reinterpret_cast<bf16x8*>(lds_dyi + (q >> 2) * K::DYI_REGION +
+                                                       ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 3) * 16) = o;
+                    }
+                    if (own && inside) {
+                        const size_t pixel = (size_t)(unsigned)((cur.b * p.H + gy) * p.W + gx);
+                        // masked sample: the state gradients pass through unchanged
+                        *reinterpret_cast<bf16x2*>(static_cast<T*>(p.dc_prev) + pixel * F_ + 2 * q) = bf16x2{(T)dcp[0], (T)dcp[1]};
+                        if (!live) {
+                            *reinterpret_cast<unsigned*>(static_cast<T*>(p.dh_prev) + pixel * F_ + 2 * q) = u_dh;
+                            if (p.dx && !p.dx_accumulate) {
+                                // dx of a masked sample is zero: this thread clears its share of the pixel's channels
+                                for (int c = 2 * q; c < p.dx_channels; c += 16)
+                                    *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + pixel * p.dx_cstride + c) = 0u;
+                            }
+                        } else if (p.hist > 0) {
+                            // dY at the pixels the history taps reach, kept for the tap weights' gradient
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int tx = hp[2 * i] - gx + 1, ty = hp[2 * i + 1] - gy + 1;
+                                if (i < p.hist && hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u)
+                                    *reinterpret_cast<bf16x8*>(static_cast<T*>(p.hist_dy) +
+                                                               ((((size_t)cur.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 8) = o;
+                            }
+                        }
+                    }
+                }
+                load_pw(nxt, std::integral_constant<int, j>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, K::NPW>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int j = I;
+                int inf = xinfo[j];
+                asm volatile("" : "+v"(inf));
+                if (live && inf < 0) {
+                    const bool inside = (cur_x_inside >> j) & 1u;
+                    *reinterpret_cast<uint4*>(lds_in + (inf & 0x3ffff)) = inside ? sx[j] : make_uint4(0u, 0u, 0u, 0u);
+                }
+                load_x(nxt, std::integral_constant<int, j>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, K::NXP>{});
+        __syncthreads();
+
+        if (live) {
+            // ---------------- phase B1: data gradient of this wave's tile row ----------------
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#ifndef ISG_BWD_NO_DGRAD  // diagnostic builds leave a phase out to see what the others take
+            {
+                const char* bb = lds_dyh + (dg_row * HALO_W + px_l) * K::DY_PSTRIDE + half * 16;
+                const char* aw = lds_w + (size_t)dg_mt * K::NS * 1024 + lane * 16;
+                bf16x8 a[2], b[2];
+                auto fetch = [&](int s, int slot) {
+                    const int tap = s >> 2, qk = s & 3;
+                    a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
+                    b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int s = 0; s < K::NS; ++s) {
+                    if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#endif
+            if (e_in) {
+#pragma unroll
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
+                    const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
+                    if (cc0 < C0) {
+                        if (p.dx && cc0 < p.dx_channels) {
+                            if (p.dx_accumulate) {
+                                v[0] += bf_lo(pre[a4].x), v[1] += bf_hi(pre[a4].x);
+                                v[2] += bf_lo(pre[a4].y), v[3] += bf_hi(pre[a4].y);
+                            }
+                            store4(static_cast<T*>(p.dx) + epixel * p.dx_cstride + cc0, v);
+                        }
+                    } else if (cc0 < C0 + F_) {
+                        store4(static_cast<T*>(p.dh_prev) + epixel * F_ + (cc0 - C0), v);
+                    }
+                }
+            }
+
+            // ---------------- phase B2: weight gradient, this wave's taps x column half ----------------
+#ifndef ISG_BWD_NO_WGRAD
+            {
+                // k-step = 16 consecutive pixels of a tile row.  Both operands come out of pixel-major LDS images
+                // through the transposing read; every address is this lane's fixed base plus a compile-time
+                // offset, and the fragments of the next k-step are requested before this one's MFMAs.
+                constexpr int NBUF = MT == 1 ? 2 : 1;  // the two-row-tile kernel has no registers for a second set
+                bf16x8 bq[NBUF], aq[NBUF][K::NSLOT];
+                auto tr_pair = [](const char* a0) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::RSTRIDE));
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    return __builtin_bit_cast(bf16x8, both);
+                };
+                auto fetch = [&](int ks, int slot) {
+                    const int r = ks >> 1, x0 = 16 * (ks & 1);
+                    bq[slot] = tr_pair(wg_dy + (r * TW + x0) * K::RSTRIDE);
+#pragma unroll
+                    for (int i = 0; i < K::NSLOT; ++i)
+                        if (i < K::NSLOT - 1 || wg_full) aq[slot][i] = tr_pair(wg_in[i] + (r * HALO_W + x0) * K::RSTRIDE);
+                };
+                if constexpr (NBUF == 2) fetch(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 2 * TR; ++ks) {
+                    const int cs = NBUF == 2 ? ks & 1 : 0;
+                    if constexpr (NBUF == 2) {
+                        if (ks + 1 < 2 * TR) fetch(ks + 1, cs ^ 1);
+                    } else {
+                        fetch(ks, 0);
+                    }
+                    if (wg_grp == 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) bsum += (float)bq[cs][jj];
+                    }
+#pragma unroll
+                    for (int i = 0; i < K::NSLOT; ++i)
+                        if (i < K::NSLOT - 1 || wg_full)
+                            wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cs][i], bq[cs], wacc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#endif
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- this workgroup's partial sums ----
+    float* slab = p.slab + (size_t)blockIdx.x * 9 * (MT * 32) * NG;
+#pragma unroll
+    for (int i = 0; i < K::NSLOT; ++i) {
+        if (i < wg_cnt) {
+            const int pair = wg_first + i;
+            const int tap = MT == 1 ? pair : pair >> 1, mt = MT == 1 ? 0 : pair & 1;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * wg_n + (lane & 31);
+                *dst = p.slab_accumulate ? *dst + wacc[i][reg] : wacc[i][reg];
+            }
+        }
+    }
+    if (wg_grp == 0) {
+        const float v = bsum + __shfl_xor(bsum, 32);
+        if (half == 0) {
+            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * wg_n + lane;
+            *dst = p.slab_accumulate ? *dst + v : v;
+        }
+    }
+}
+
+// dw_x[tap][C + i][:] (+)= sum over samples of the dY rows the fused kernel filed per (sample, frame, tap)
+__global__ __launch_bounds__(256) void hist_side_wgrad_kernel(const __bf16* __restrict__ hist_dy, int B, int hist, int C,
+                                                              int accumulate, float* __restrict__ dw_x) {
+    __shared__ float red[4][NG];
+    const int tap = blockIdx.x / hist, i = blockIdx.x - tap * hist;
+    const int k = threadIdx.x & (NG - 1), sg = threadIdx.x >> 6;
+    float sum = 0.0f;
+    for (int b = sg; b < B; b += 4) sum += (float)hist_dy[(((size_t)b * hist + i) * 9 + tap) * NG + k];
+    red[sg][k] = sum;
+    __syncthreads();
+    if (sg == 0) {
+        sum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        float* dst = dw_x + ((size_t)tap * (C + hist) + C + i) * NG + (k & 3) * F_ + (k >> 2);
+        *dst = accumulate ? *dst + sum : sum;
+    }
+}
+
+template <int C0, int MT, int TR>
+int launch_bwd(BwdParams p, int num_cus, hipStream_t stream) {
+    using K = FB<C0, MT, TR>;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TR - 1) / TR;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
+    const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
+    const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
+    (void)num_cus;
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream, p);
+    return isg::check_launch("convlstm_bwd_fused_kernel");
+}
+
+int bwd_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+bool bwd_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
+    return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32) && hist >= 0 && hist <= 2 && B >= 1 && H >= 1 && W >= 1 &&
+           (long long)B * H * W * 128 < (1LL << 32);
+}
+
+}  // namespace
+
+extern "C" int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
+    return bwd_supported(Cs, F, dtype, B, H, W, hist) ? 1 : 0;
+}
+
+extern "C" long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist) {
+    return (long long)B * hist * 9 * NG * 2;
+}
+
+extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
+                                      long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                                      const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
+                                      int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
+                                      int t, const int32_t* hist_points, int hist, long long hist_batch_stride,
+                                      void* hist_scratch, void* dc_prev, void* dh_prev, void* dx, int dx_channels,
+                                      int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
+                                      void* stream) {
+    ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
+                "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16 or 32, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
+                "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
+    ISG_REQUIRE(gates && c_prev && c_cur && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
+                    dh_state && dc_state, ISG_EINVAL, "isg_convlstm_bwd_fused: null pointer");
+    ISG_REQUIRE(dc_prev != dc_state && dh_prev != dh_state, ISG_EINVAL,
+                "isg_convlstm_bwd_fused: dc_prev / dh_prev must not alias dc_state / dh_state (neighbouring tiles read "
+                "the incoming gradients of each other's border pixels)");
+    ISG_REQUIRE(mode == ISG_WGRAD_DEFER_FIRST || mode == ISG_WGRAD_DEFER, ISG_EINVAL,
+                "isg_convlstm_bwd_fused: the partial sums stay in the workspace (mode ISG_WGRAD_DEFER_FIRST or ISG_WGRAD_DEFER)");
+    ISG_REQUIRE(C >= 1 && C <= Cs, ISG_EINVAL, "isg_convlstm_bwd_fused: bad channel count");
+    ISG_REQUIRE(dh_above_pool >= 1 && (dh_above_pool & (dh_above_pool - 1)) == 0 && H % dh_above_pool == 0 &&
+                    W % dh_above_pool == 0, ISG_EINVAL,
+                "isg_convlstm_bwd_fused: pool %d must be a power of two that divides the %dx%d grid", dh_above_pool, H, W);
+    int pool_shift = 0;
+    while ((1 << pool_shift) < dh_above_pool) ++pool_shift;
+    ISG_REQUIRE(!dx || (dx_channels >= 4 && dx_channels % 4 == 0 && dx_channels <= Cs && dx_channel_stride % 4 == 0 &&
+                        dx_channel_stride >= dx_channels),
+                ISG_EINVAL, "isg_convlstm_bwd_fused: dx channels/stride must be multiples of 4 within the input width");
+    ISG_REQUIRE(hist == 0 || (hist_points && hist_scratch && dw_x), ISG_EINVAL,
+                "isg_convlstm_bwd_fused: history points, scratch and dw_x are needed when hist > 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int MT = (Cs + F_ + 31) / 32;
+    BwdParams p = {};
+    p.gates = gates, p.c_prev = c_prev, p.c_cur = c_cur;
+    p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
+    p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
+    p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;
+    p.dc_prev = dc_prev, p.dh_prev = dh_prev;
+    p.dx = dx, p.dx_channels = dx ? dx_channels : 0, p.dx_cstride = dx_channel_stride, p.dx_accumulate = dx_accumulate;
+    p.slab = static_cast<float*>(workspace);
+    p.bias_slab = p.slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
+    p.slab_accumulate = mode == ISG_WGRAD_DEFER;
+    p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_dy = hist_scratch;
+    if (hist > 0) {
+        hipError_t e = hipMemsetAsync(hist_scratch, 0, (size_t)isg_convlstm_bwd_fused_hist_bytes(B, hist), s);
+        ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    int rc = Cs == 16 ? launch_bwd<16, 1, 8>(p, bwd_num_cus(), s) : launch_bwd<32, 2, 4>(p, bwd_num_cus(), s);
+    if (rc != ISG_OK) return rc;
+    if (hist > 0) {
+        hipLaunchKernelGGL(hist_side_wgrad_kernel, dim3(9 * hist), dim3(256), 0, s, static_cast<const __bf16*>(hist_scratch), B,
+                           hist, C, mode == ISG_WGRAD_DEFER ? 1 : 0, dw_x);
+        rc = isg::check_launch("hist_side_wgrad_kernel");
+    }
+    return rc;
+}

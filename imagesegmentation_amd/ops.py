@@ -306,6 +306,45 @@ def wgrad_finish(workspace, shape, c_real, hist, dw_x, dw_h, dbias, accumulate=F
     _lib.check(rc, "isg_convlstm_wgrad_finish")
 
 
+def bwd_fused_supported(packed, B, H, W):
+    """Whether the one-launch backward step exists for this cell shape (ISG_NO_FUSED_BWD=1 answers no: the
+    three-kernel backward, for A/B runs)."""
+    if os.environ.get("ISG_NO_FUSED_BWD"):
+        return False
+    return bool(_lib.lib().isg_convlstm_bwd_fused_supported(packed.cs, packed.f, dtype_code(packed.dtype), int(B), int(H),
+                                                            int(W), packed.hist))
+
+
+_hist_scratch = {}
+
+
+@_timed("bwd_fused")
+def bwd_fused(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
+              dh_prev, workspace, mode, dw_x, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0,
+              hist_points=None, pool=1):
+    """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward, data gradient (dx
+    optional, dh_prev) and weight gradient (deferred partial sums in ``workspace``; the history taps' rows of
+    ``dw_x`` directly).  dc_state / dh_state (either may be None) are read, dc_prev / dh_prev written: different
+    buffers."""
+    B, H, W, F, _ = gates.shape
+    pts, pts_stride = _points_arg(hist_points, packed.hist)
+    scratch = None
+    if packed.hist:
+        key = (B, packed.hist, str(gates.device))
+        scratch = _hist_scratch.get(key)
+        if scratch is None:
+            n = _lib.lib().isg_convlstm_bwd_fused_hist_bytes(B, packed.hist)
+            scratch = _hist_scratch[key] = torch.empty([n // 2], dtype=torch.bfloat16, device=gates.device)
+    rc = _lib.lib().isg_convlstm_bwd_fused(
+        _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(c_cur), dh_above.data_ptr() if dh_above is not None else None,
+        int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), _lib.ptr(x), _lib.ptr(h_prev),
+        _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype), _lib.ptr(durations), int(t),
+        pts, packed.hist, pts_stride, _lib.ptr(scratch), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx),
+        int(dx_channels), int(dx.shape[-1]) if dx is not None else 0, int(bool(dx_accumulate)), _lib.ptr(workspace),
+        int(mode), _lib.ptr(dw_x), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_bwd_fused")
+
+
 def avgpool(x, k):
     """Mean over k x k windows of a contiguous NHWC tensor [..., H, W, F] -> [..., H/k, W/k, F]."""
     _need_cuda(x, "x")

@@ -209,6 +209,32 @@ int isg_convlstm_wgrad(const void* x, const void* h_prev, const void* dy, int B,
 int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C, int Cs, int hist, int F,
                               int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream);
 
+/* Backward, all three steps in ONE launch (bf16): the pre-activation gradient dy is computed per tile, halo
+ * included, from the saved gates / cell states and the incoming gradients, lives only in on-chip memory, and
+ * feeds the data gradient and the weight gradient there - it is never written to or read from device memory
+ * (384 fewer bytes per pixel than isg_convlstm_pointwise_bwd + _dgrad + _wgrad).  Same results as those three
+ * calls up to the order of float additions.  Replaces the gradient of reference convLSTM.py:36-43 that
+ * tf.gradients derives (reference polyrnn/Model.py:108).
+ *   Only where isg_convlstm_bwd_fused_supported(...) returns 1: bf16, F = 16, Cs = 16 or 32, hist <= 2.
+ *   dc_state / dc_prev are bf16 and must be different buffers, as must dh_state / dh_prev (a tile recomputes its
+ *   neighbours' border pixels from the incoming gradients); for a masked sample both pass through as copies
+ *   and dx is zero (left alone when accumulating).
+ *   workspace / mode: as isg_convlstm_wgrad with ISG_WGRAD_DEFER_FIRST (overwrite) or ISG_WGRAD_DEFER (add);
+ *   close the sequence with isg_convlstm_wgrad_finish.  With hist > 0 the gradient of the history taps goes
+ *   to the hist channels of dw_x (assigned / added by the same mode) through hist_scratch, device scratch of
+ *   isg_convlstm_bwd_fused_hist_bytes(B, hist) bytes.
+ *   dh_above, dh_state and dc_state must all be given (zeros where there is no gradient); dh_above_pool is a
+ *   power of two.  Other arguments: as the three calls it replaces. */
+int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
+long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
+int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
+                           long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                           const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad, int B,
+                           int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations, int t,
+                           const int32_t* hist_points, int hist, long long hist_batch_stride, void* hist_scratch,
+                           void* dc_prev, void* dh_prev, void* dx, int dx_channels, int dx_channel_stride,
+                           int dx_accumulate, void* workspace, int mode, float* dw_x, void* stream);
+
 /* ---- vertex decoding over the class grid ----------------------------------------------------
  * logits: `dtype` [rows][cols] (cols = P*P or P*P + 1).  One wave per row.
  *

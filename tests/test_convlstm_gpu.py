@@ -455,3 +455,90 @@ def test_pooled_output_from_the_cell_kernel(C, hist):
     assert tuple(pooled_seq.shape) == (B, T, H // 8, W // 8, F)
     assert float((pooled_seq.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6
     assert float(pooled_seq[1].abs().max()) == 0.0 and float(pooled_seq[2, 2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["two_layers_points", "pooled_top", "time_major_ragged", "dense_history_wide"])
+def test_fused_backward_step_matches_the_three_kernel_backward(case, monkeypatch):
+    """isg_convlstm_bwd_fused (gate backward + data gradient + weight gradient in one launch, dY never in device
+    memory) against the pointwise / dgrad / wgrad sequence on the same saved tensors: every gradient of the
+    stacked recurrence, bf16.  Shapes with partial tiles, masked samples (duration 0 and short), initial and final
+    state gradients, the pooled head gradient, history as points (tap gradients) and as dense channels (Cs = 32)."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(31)
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    if case == "two_layers_points":
+        T, B, H, W, Cf, hist, L, pool = 4, 5, 28, 28, 16, 2, 2, 1
+    elif case == "pooled_top":
+        T, B, H, W, Cf, hist, L, pool = 3, 3, 16, 64, 32, 1, 2, 8
+    elif case == "time_major_ragged":
+        T, B, H, W, Cf, hist, L, pool = 3, 4, 19, 37, 16, 0, 3, 1
+    else:
+        T, B, H, W, Cf, hist, L, pool = 3, 3, 12, 40, 16, 2, 1, 1
+    durations = np.array([T, 0, 2, 1, T][:B], np.int32)
+    dense = case == "dense_history_wide"
+    C_in = Cf if case == "time_major_ragged" else Cf + hist
+    _, multi = _stack(rs, C_in, L, dtype, (H, W))
+    feat = rs.randn(B, H, W, Cf)
+    x_seq = rs.randn(T, B, H, W, Cf)
+    pts = rs.randint(0, min(H, W), [B, T, max(hist, 1), 2]).astype(np.int32)[:, :, :hist]
+    if hist:
+        pts[0, 0, 0] = (-1, -1)       # an empty frame
+        pts[2, 0, 0] = (W - 1, 0)     # taps that fall off the image
+    frames = np.zeros([B, T, H, W, hist])
+    for b in range(B):
+        for s in range(T):
+            for i in range(hist):
+                if pts[b, s, i, 0] >= 0:
+                    frames[b, s, pts[b, s, i, 1], pts[b, s, i, 0], i] = 1
+    init = [(rs.randn(B, H, W, 16) * 0.3, rs.randn(B, H, W, 16) * 0.3) for _ in range(L)]
+    d_out = rs.randn(B, T, H // pool, W // pool, 16)
+    d_fin = [(rs.randn(B, H, W, 16), rs.randn(B, H, W, 16)) for _ in range(L)]
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("ISG_NO_FUSED_BWD", raising=False)
+        else:
+            monkeypatch.setenv("ISG_NO_FUSED_BWD", "1")
+        for cell in multi.cells:
+            for prm in (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias):
+                prm.grad = None
+        tinit = tuple((t(c).requires_grad_(True), t(h, dtype).requires_grad_(True)) for c, h in init)
+        if case == "time_major_ragged":
+            inp = t(x_seq, dtype).requires_grad_(True)
+            out, final = dynamic_rnn(multi, inp, sequence_length=durations, initial_state=tinit, time_major=False
+                                     if False else True)
+            out = out.transpose(0, 1)
+            leaf = inp
+        else:
+            leaf = t(feat, dtype).requires_grad_(True)
+            seq = SequenceInput(static=leaf, hist_dense=t(frames, dtype)) if dense else \
+                SequenceInput(static=leaf, hist_points=torch.tensor(pts, device=dev()))
+            out, final = dynamic_rnn(multi, seq, sequence_length=durations, initial_state=tinit, time_major=False,
+                                     output_pool=pool)
+        loss = (out.float() * t(d_out)).sum()
+        for l in range(L):
+            loss = loss + (final[l].c * t(d_fin[l][0])).sum() + (final[l].h.float() * t(d_fin[l][1])).sum()
+        calls = []
+        real = ops.bwd_fused
+        monkeypatch.setattr(ops, "bwd_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        loss.backward()
+        monkeypatch.setattr(ops, "bwd_fused", real)
+        got = {"leaf": leaf.grad.float().clone()}
+        for l, cell in enumerate(multi.cells):
+            got["w_x%d" % l] = cell.input_to_state_kernel.grad.clone()
+            got["w_h%d" % l] = cell.hidden_to_state_kernel.grad.clone()
+            got["b%d" % l] = cell.bias.grad.clone()
+            got["dc0_%d" % l] = tinit[l][0].grad.float().clone()
+            got["dh0_%d" % l] = tinit[l][1].grad.float().clone()
+        return got, len(calls)
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == L * int(durations.max())
+    for key in ref:
+        scale = max(float(ref[key].abs().max()), 1e-6)
+        err = float((got[key] - ref[key]).abs().max()) / scale
+        assert err <= 1e-2, "%s: fused backward differs from the three-kernel backward by %.3e of max" % (key, err)
+        assert torch.isfinite(got[key]).all()
