@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 constexpr int j = I;
                 int inf = pinfo[j];
                 asm volatile("" : "+v"(inf));
-                if (cur.valid && inf < 0) {
+                if (live && inf < 0) {
                     const int hy = inf & 0xff, hx = (inf >> 8) & 0xff;
                     const bool inside = (cur_pw_inside >> j) & 1u;
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
                     if (false) {
 #else
-                    if (live && inside) {
+                    if (inside) {
 #endif
                         const float gv[8] = {bf_lo(sg[j].x), bf_hi(sg[j].x), bf_lo(sg[j].y), bf_hi(sg[j].y),
                                              bf_lo(sg[j].z), bf_hi(sg[j].z), bf_lo(sg[j].w), bf_hi(sg[j].w)};
@@ -319,25 +319,15 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         }
                     }
                     const bf16x8 o = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
-                    if (live) {
-                        const int px = hy * HALO_W + hx;
-                        *reinterpret_cast<bf16x8*>(lds_dyh + px * K::DY_PSTRIDE + q * 16) = o;
-                        if (own)
-                            *reinterpret_cast<bf16x8*>(lds_dyi + (q >> 2) * K::DYI_REGION +
-                                                       ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 3) * 16) = o;
-                    }
+                    *reinterpret_cast<bf16x8*>(lds_dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 16) = o;
+                    if (own)
+                        *reinterpret_cast<bf16x8*>(lds_dyi + (q >> 2) * K::DYI_REGION +
+                                                   ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 3) * 16) = o;
                     if (own && inside) {
-                        const size_t pixel = (size_t)(unsigned)((cur.b * p.H + gy) * p.W + gx);
-                        // masked sample: the state gradients pass through unchanged
-                        *reinterpret_cast<bf16x2*>(static_cast<T*>(p.dc_prev) + pixel * F_ + 2 * q) = bf16x2{(T)dcp[0], (T)dcp[1]};
-                        if (!live) {
-                            *reinterpret_cast<unsigned*>(static_cast<T*>(p.dh_prev) + pixel * F_ + 2 * q) = u_dh;
-                            if (p.dx && !p.dx_accumulate) {
-                                // dx of a masked sample is zero: this thread clears its share of the pixel's channels
-                                for (int c = 2 * q; c < p.dx_channels; c += 16)
-                                    *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + pixel * p.dx_cstride + c) = 0u;
-                            }
-                        } else if (p.hist > 0) {
+                        const unsigned pixel = (unsigned)((cur.b * p.H + gy) * p.W + gx);
+                        *reinterpret_cast<bf16x2*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 4u)) =
+                            bf16x2{(T)dcp[0], (T)dcp[1]};
+                        if (p.hist > 0) {
                             // dY at the pixels the history taps reach, kept for the tap weights' gradient
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
@@ -364,6 +354,25 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 load_x(nxt, std::integral_constant<int, j>{});
             }(), ...);
         }(std::make_integer_sequence<int, K::NXP>{});
+        if (cur.valid && !live) {
+            // A masked sample (t >= its length): the state gradients pass through as copies and dx is zero.  Rare,
+            // so it reads what it needs itself instead of widening the staged path above.
+            for (int i = tid; i < TR * TW * 8; i += kBwdThreads) {
+                const int pix = i >> 3, qq = i & 7;
+                const int gy = cur.ty0 + pix / TW, gx = cur.tx0 + (pix & (TW - 1));
+                if (gy < p.H && gx < p.W) {
+                    const unsigned pixel = (unsigned)((cur.b * p.H + gy) * p.W + gx);
+                    const size_t so = (size_t)(pixel * 32u + qq * 4u);
+                    *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
+                        *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
+                    *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
+                        *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
+                    if (p.dx && !p.dx_accumulate)
+                        for (int c = 2 * qq; c < p.dx_channels; c += 16)
+                            *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + (size_t)pixel * p.dx_cstride + c) = 0u;
+                }
+            }
+        }
         __syncthreads();
 
         if (live) {
