@@ -58,6 +58,8 @@ def parse():
                     help="no GPU work: every rank joins the process group (ISG_DIST_BACKEND, default nccl), runs the "
                          "timed region's fences and reductions around an empty step on host tensors, and rank 0 prints "
                          "a JSON line - checks the multi-rank launch path on a machine without GPUs")
+    ap.add_argument("--no-extra-runs", action="store_true",
+                    help="skip the two extra training legs (every sequence at full length; the same step in f32)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
     return ap.parse_args()
@@ -136,12 +138,32 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         kernels = [
             ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts), flops,
              px * (x_b + h_b + c_b + h_b + c_b + g_b)),
-            ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
-             0.0, px * (2 * g_b + 2 * h_b + 2 * c_b + 2 * h_b)),  # the dc carry is stored like dh
-            ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, px * (g_b + x_b + h_b)),
-            ("wgrad", lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, accumulate=False, hist_points=pts, hist=hist),
-             flops, px * (x_b + h_b + g_b)),
         ]
+        top = l == len(model.rnn.cells) - 1
+        pool = P // model.head_size if top else 1
+        if ops.bwd_fused_supported(packed, B, P, P):
+            # one launch: gates, both cell states and the three incoming gradients in (the top layer's comes from
+            # the pooled head grid), [x | h_prev] in, dc_prev / dh_prev / dx out (layer 0 adds to its running dx)
+            above = torch.randn([B, P // pool, P // pool, F], device=dev).to(dt)
+            dcn, dhn = torch.empty_like(dc), torch.empty_like(dh)
+            ws = ops.wgrad_workspace(cs, F, dev, cached=False)
+            dx_ch = cs if hist else F
+            dx_f = torch.zeros([B, P, P, dx_ch], dtype=dt, device=dev)
+            acc_dx = l == 0
+            dx_b = dx_ch * esz * (2 if acc_dx else 1)
+            kernels.append(("bwd_fused", lambda: ops.bwd_fused(gates, c, c2, above, (P // pool) ** 2 * F, dh, dc, x, h, packed,
+                                                                dcn, dhn, ws, ops.WGRAD_DEFER, dwx, dx=dx_f,
+                                                                dx_channels=dx_ch, dx_accumulate=acc_dx, hist_points=pts,
+                                                                pool=pool),
+                            2.0 * flops, px * (g_b + 2 * c_b + h_b / (pool * pool) + 2 * h_b + x_b + h_b + 2 * h_b + dx_b)))
+        else:
+            kernels += [
+                ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),
+                 0.0, px * (2 * g_b + 2 * h_b + 2 * c_b + 2 * h_b)),  # the dc carry is stored like dh
+                ("dgrad", lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs), flops, px * (g_b + x_b + h_b)),
+                ("wgrad", lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, accumulate=False, hist_points=pts, hist=hist),
+                 flops, px * (x_b + h_b + g_b)),
+            ]
         for name, fn, work, nbytes in kernels:
             ms_isolated = event_time_ms(fn, reps)
             # duration inside the training step (events around the same launch in two extra steps) when known:
@@ -224,13 +246,30 @@ def bench_a3c(n_envs, steps, device, rank, dtype):
             "loss": trainer.last["loss"]}
 
 
+def csrc_hash():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h): the counter passes are stamped with it."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "imagesegmentation_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic():
     """HBM bytes per launch from the committed counter passes (FETCH_SIZE and WRITE_SIZE need a profiler
-    run each, so they cannot be read inside the timed run): {kernel label: bytes}, empty when absent."""
+    run each, so they cannot be read inside the timed run): {kernel label: bytes}.  Empty when the file is
+    absent or was taken with other kernel sources than the ones in the tree (its csrc_hash stamp)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return {k: v["hbm_bytes"] for k, v in json.load(f)["kernels"].items()}
+            rec = json.load(f)
+        if rec.get("csrc_hash") != csrc_hash():
+            return {}
+        return {k: v["hbm_bytes"] for k, v in rec["kernels"].items()}
     except (OSError, ValueError, KeyError):
         return {}
 
@@ -336,7 +375,8 @@ def bench_raster(n, size, steps, warmup, device, rank, do_cpu):
 def note(msg):
     """Progress on stderr (stdout carries the one JSON line): a long silent run looks hung to a supervisor."""
     if int(os.environ.get("RANK", "0")) == 0:
-        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+        mem = torch.cuda.memory_allocated() / 2 ** 30 if torch.cuda.is_initialized() else 0.0
+        print("[bench %6.1f s, %5.1f GiB held] %s" % (time.perf_counter() - _T0, mem, msg), file=sys.stderr, flush=True)
 
 
 _T0 = time.perf_counter()
@@ -515,28 +555,64 @@ def main():
         traffic = load_pmc_traffic() if default_shape else {}
         for k in kernels:
             k["traffic"] = traffic.get(k["kernel"])
-        # The dominant kernel = the GPU function with the most time in a step.  Every label below runs T times per
-        # step; the two pointwise labels are ONE function (same symbol for both layers), each convolution label is
-        # its own template instantiation.
-        groups = {}
-        for k in kernels:
-            sym = "lstm_pointwise_bwd_kernel" if k["kernel"].startswith("pointwise_bwd") else k["kernel"]
-            groups.setdefault(sym, []).append(k)
-        sym, members = max(groups.items(), key=lambda kv: sum(m["ms"] for m in kv[1]))
-        ms = sum(m["ms"] for m in members) / len(members)
-        nbytes = sum(m["bytes"] for m in members) / len(members)
-        flops = sum(m["flops"] for m in members) / len(members)
-        traffic = [m["traffic"] for m in members]
-        dom = members[0]
-        achieved = nbytes / ms / 1e6 if dom["bound"] == "hbm" else flops / ms / 1e9
-        roofline = {"bound": dom["bound"], "achieved": achieved, "peak": dom["peak"], "unit": dom["unit"],
-                    "frac": achieved / dom["peak"],
-                    "traffic": None if any(t is None for t in traffic) else sum(traffic) / len(traffic),
-                    "kernel": sym if len(members) > 1 else dom["kernel"], "launches_per_step": len(members) * T,
-                    "ms_per_launch": ms, "algorithmic_bytes": nbytes, "flops": flops}
+        # The dominant kernel = the GPU function with the most time in a step.  Every label below is its own
+        # template instantiation and runs T times per step.
+        dom = max(kernels, key=lambda k: k["ms"])
+        roofline = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                    "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["kernel"],
+                    "symbol": {"bwd_fused": "convlstm_bwd_fused_kernel", "cell_fwd": "conv3x3_pp_kernel",
+                               "pointwise_bwd": "lstm_pointwise_bwd_kernel", "dgrad": "conv3x3_pp_kernel",
+                               "wgrad": "conv_wgrad_pp_kernel"}.get(dom["kernel"].split("[")[0]),
+                    "launches_per_step": T, "ms_per_launch": dom["ms"], "algorithmic_bytes": dom["bytes"],
+                    "flops": dom["flops"], "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("CPU baseline of the training step (bounded sample)")
         cpu = cpu_baseline_convlstm(model, batch, size, T, hist, head_size)
+
+    extra = None
+    if not args.no_extra_runs:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra = {}
+        note("extra leg: every sequence at full length (durations = T)")
+        full = np.full_like(batch["durations"], T)
+
+        def time_steps(m, bt, durations, n, warm):
+            for _ in range(warm):
+                m.train_step(bt["images"], durations, bt["points"], bt["targets"])
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                m.train_step(bt["images"], durations, bt["points"], bt["targets"])
+            fence()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tm = torch.tensor([el], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                el = float(tm.item())
+            return el / n
+
+        conv_flops = lambda m, dur: 3.0 * sum(2.0 * size * size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
+                                              for c in m.rnn.cells) * float(np.mean(dur))
+        sec = time_steps(model, batch, full, max(args.steps // 2, 3), 1)
+        extra["all_durations_T"] = {"value": args.batch * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                                    "dtype": args.dtype, "convlstm_mfma_frac_of_step":
+                                        conv_flops(model, full) * args.batch / sec / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]}
+        if args.dtype == "bf16":
+            note("extra leg: the same step in f32 (f32 MFMA, three-kernel backward)")
+            find = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = False  # no solver search for a three-step leg
+            m32 = experiments.make("RNNConv", image_size=size, compute_dtype=torch.float32, device=device, seed=0,
+                                   head_size=head_size)
+            b32 = dict(batch, images=batch["images"].float())
+            sec = time_steps(m32, b32, batch["durations"], 3, 1)
+            extra["f32"] = {"value": args.batch * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                            "dtype": "f32", "convlstm_mfma_frac_of_step":
+                                conv_flops(m32, batch["durations"]) * args.batch / sec / 1e12 / MFMA_PEAK_TFLOPS["f32"]}
+            del m32, b32
+            torch.backends.cudnn.benchmark = find
+            torch.cuda.empty_cache()
 
     if rank == 0:
         flop_seq = 3.0 * sum(2.0 * size * size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
@@ -555,7 +631,7 @@ def main():
             "convlstm_mfma_frac_of_step": flop_seq * args.batch * world / (elapsed / args.steps) / 1e12 /
             (MFMA_PEAK_TFLOPS[args.dtype] * world),
             "loss": float(loss),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "extra_runs": extra,
             "iou": raster, "reinforce": rl, "a3c": ac,
         }
         print(json.dumps(line))

@@ -512,6 +512,10 @@ class _SequenceFunction(torch.autograd.Function):
             result += [None if cd is None else dc_state[l].to(cd), None if hd is None else dh_state[l].to(hd)]
         for l in range(L):
             result += list(grads[l])
+        # The returned final states are entries of the saved buffers, whose grad_fn is this node: a reference cycle
+        # through ctx.saved that only the garbage collector would break, gigabytes at a time.  Nothing runs
+        # backward through this node twice.
+        ctx.saved = ctx.seq = ctx.multi = None
         return tuple(result)
 
 

@@ -46,6 +46,8 @@ def per_label(rows):
             assert len(values) == CALLS * per_call, (label, len(values))
             out[label] = sum(values) / CALLS
 
+    put("bwd_fused[layer0 C=33]", pick("convlstm_bwd_fused_kernel<32, 2, 4"))
+    put("bwd_fused[layer1 C=16]", pick("convlstm_bwd_fused_kernel<16, 1, 8"))
     put("cell_fwd[layer0 C=33]", pick("conv3x3_pp_kernel<32, 16, 2, 0"))
     put("cell_fwd[layer1 C=16]", pick("conv3x3_pp_kernel<16, 16, 2, 0"))
     pw = pick("lstm_pointwise_bwd_kernel")
@@ -70,7 +72,9 @@ def main():
         rd, wr = 2.0 * fetch[label] * 1024.0, write.get(label, 0.0) * 1024.0
         kernels[label] = {"fetch_size_kib": fetch[label], "write_size_kib": write.get(label),
                           "read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr}
-    json.dump({"note": "per launch; read_bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench  # for the fingerprint of the kernel sources these numbers belong to
+    json.dump({"csrc_hash": bench.csrc_hash(), "note": "per launch; read_bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), "
                        "write_bytes = WRITE_SIZE x 1024; from bench.py --kernels-only at the default workload",
                "kernels": kernels}, sys.stdout, indent=1)
     print()
