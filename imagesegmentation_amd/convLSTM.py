@@ -519,28 +519,158 @@ class _SequenceFunction(torch.autograd.Function):
         return tuple(result)
 
 
-def _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state):
-    """Step-by-step recurrence through ``cell.forward`` (autograd records every step); used for
-    cells wider than 16 filters, which the fused sequence node does not take.  Same masking rule:
-    past a sample's length the output is zero and the state is carried through."""
-    if seq.x_seq is None:
-        raise NotImplementedError("wide cells take a time-major tensor input")
-    state = [LSTMStateTuple(c, h) for c, h in initial_state]
-    dt = multi.cells[0].compute_dtype
-    outs = []
-    for t in range(seq.T):
-        if t >= t_run:
-            outs.append(torch.zeros([seq.B, seq.H, seq.W, multi.cells[-1]._filters], dtype=dt, device=seq.x_seq.device))
-            continue
-        x, new_state = multi(seq.x_seq[t], tuple(state))
-        if durations_dev is not None:
-            live = (durations_dev > t).view(-1, 1, 1, 1)
-            x = torch.where(live, x, torch.zeros_like(x))
-            new_state = [LSTMStateTuple(torch.where(live, n.c, o.c.to(n.c.dtype)), torch.where(live, n.h, o.h.to(n.h.dtype)))
-                         for n, o in zip(new_state, state)]
-        state = list(new_state)
-        outs.append(x)
-    return torch.stack(outs, dim=1), tuple(state)
+def _wide_groups(cell, C):
+    """A cell of 16 k filters (k > 1) as k groups of 16: the output channels [16 s, 16 s + 16) depend on all of
+    x and all of h_prev but on no other output channel, so group s is a 16-filter cell whose input is x joined
+    with h_prev[16:] (their weights joined the same way), whose recurrent input is h_prev[:16], and whose gate
+    columns are the group's columns of each j|i|f|o block.  The groups' packed weight images are cached until
+    the weights change."""
+    params = (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias)
+    key = tuple((p.data_ptr(), p._version) for p in params) + (cell.compute_dtype, ops.weights_epoch())
+    cached = getattr(cell, "_wide_cache", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
+    cw = C + F - Fh
+    if cw > 64 - Fh:
+        raise NotImplementedError("a %d-filter cell takes at most %d input channels" % (F, 64 - F))
+    groups = []
+    with torch.no_grad():
+        for s in range(F // Fh):
+            cols = torch.cat([torch.arange(g * F + Fh * s, g * F + Fh * s + Fh) for g in range(4)]).to(params[0].device)
+            w_h_cols = params[1].index_select(3, cols)
+            w_x = torch.cat([params[0].index_select(3, cols), w_h_cols[:, :, Fh:]], dim=2).contiguous()
+            packed = ops.PackedWeights(w_x, w_h_cols[:, :, :Fh].contiguous(), params[2].index_select(0, cols),
+                                       ops.padded_channels(cw, dt), dt)
+            groups.append((cols, packed))
+    cell._wide_cache = (key, groups)
+    return groups
+
+
+class _WideSequenceFunction(torch.autograd.Function):
+    """dynamic_rnn of ONE cell of 16 k filters as one autograd node: per step one fused forward launch per group
+    on a shared [x | h_prev[16:]] buffer, and a hand-written reverse sweep with the 16-filter backward kernels.
+    The state is kept per group ([B, H, W, 16] each) so that nothing is sliced or re-packed inside the loops."""
+
+    @staticmethod
+    def forward(ctx, cell, durations_dev, t_run, x_seq, c0, h0, w_x, w_h, bias):
+        T, B, H, W, C = x_seq.shape
+        Fh, F, dt, dev = ops.F_HIDDEN, cell._filters, cell.compute_dtype, x_seq.device
+        k = F // Fh
+        groups = _wide_groups(cell, C)
+        cs = groups[0][1].cs
+        xw = torch.zeros([max(t_run, 1), B, H, W, cs], dtype=dt, device=dev)
+        xw[:t_run, ..., :C] = x_seq[:t_run].to(dt)
+        Hs = [[h0[..., Fh * s:Fh * s + Fh].to(dt).contiguous()] +
+              list(torch.empty([t_run, B, H, W, Fh], dtype=dt, device=dev).unbind(0)) for s in range(k)]
+        Cs = [[c0[..., Fh * s:Fh * s + Fh].to(torch.float32).contiguous()] +
+              list(torch.empty([t_run, B, H, W, Fh], dtype=torch.float32, device=dev).unbind(0)) for s in range(k)]
+        Gs = [torch.empty([t_run, B, H, W, Fh, 4], dtype=dt, device=dev) for _ in range(k)]
+        outs = [torch.zeros([B, T, H, W, Fh], dtype=dt, device=dev) for _ in range(k)]
+        live = None
+        for t in range(t_run):
+            for s in range(1, k):
+                xw[t, ..., C + Fh * (s - 1):C + Fh * s] = Hs[s][t]
+            if durations_dev is not None:
+                live = (durations_dev > t).view(-1, 1, 1, 1)
+            for s in range(k):
+                ops.cell_fwd(xw[t], Hs[0][t], Cs[s][t], groups[s][1], durations_dev, t, out=outs[s][:, t],
+                             out_batch_stride=T * H * W * Fh, save_gates=False, h_out=Hs[s][t + 1], c_out=Cs[s][t + 1],
+                             gates=Gs[s][t])
+                if s > 0 and live is not None:
+                    # a finished sample's state passes through; the kernel copied its RECURRENT input (group 0's h)
+                    Hs[s][t + 1].copy_(torch.where(live, Hs[s][t + 1], Hs[s][t]))
+        ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C = cell, durations_dev, t_run, C
+        ctx.saved = (xw, Hs, Cs, Gs, groups)
+        ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
+        ctx.set_materialize_grads(False)
+        out = torch.cat(outs, dim=-1)
+        return out, torch.cat([Cs[s][t_run] for s in range(k)], dim=-1), torch.cat([Hs[s][t_run] for s in range(k)], dim=-1)
+
+    @staticmethod
+    def backward(ctx, d_out, d_c, d_h):
+        cell, durations_dev, t_run, C = ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C
+        xw, Hs, Cs, Gs, groups = ctx.saved
+        Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
+        k = F // Fh
+        _, B, H, W, cs = xw.shape
+        dev = xw.device
+        T = d_out.shape[1] if d_out is not None else t_run
+        part = lambda g, s, d: (g[..., Fh * s:Fh * s + Fh].to(d).contiguous() if g is not None else
+                                torch.zeros([B, H, W, Fh], dtype=d, device=dev))
+        dc_state = [part(d_c, s, torch.float32) for s in range(k)]
+        dh_state = [part(d_h, s, dt) for s in range(k)]
+        if d_out is not None:  # group-major, one copy for the whole sequence
+            d_out_g = d_out.to(dt).reshape(B, T, H, W, k, Fh).permute(4, 0, 1, 2, 3, 5).contiguous()
+        else:
+            d_out_g = torch.zeros([k, B, T, H, W, Fh], dtype=dt, device=dev)
+        d_x = torch.zeros([T, B, H, W, C], dtype=dt, device=dev)
+        dy = torch.empty([B, H, W, Fh, 4], dtype=dt, device=dev)
+        dxw = torch.empty([B, H, W, cs], dtype=dt, device=dev)
+        dh_extra = torch.zeros([B, H, W, Fh], dtype=dt, device=dev)
+        gw = [(torch.zeros([3, 3, C + F - Fh, 4 * Fh], dtype=torch.float32, device=dev),
+               torch.zeros([3, 3, Fh, 4 * Fh], dtype=torch.float32, device=dev),
+               torch.zeros([4 * Fh], dtype=torch.float32, device=dev)) for _ in range(k)]
+        slabs = [ops.wgrad_workspace(cs, Fh, dev, cached=False) for _ in range(k)]
+        for t in reversed(range(t_run)):
+            live = (durations_dev > t).view(-1, 1, 1, 1) if durations_dev is not None else None
+            mode = ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST
+            dh0_sum = None
+            for s in range(k):
+                ops.pointwise_bwd(Gs[s][t], Cs[s][t], Cs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s], dc_state[s],
+                                  durations_dev, t, dy=dy, dc_prev=dc_state[s])
+                ops.wgrad(xw[t], Hs[0][t], dy, C + F - Fh, gw[s][0], gw[s][1], gw[s][2], True, durations_dev, t, mode=mode,
+                          workspace=slabs[s])
+                # every group's recurrent input is group 0's h: its gradient is the sum over the groups.  Group 0
+                # writes into its own carried buffer (a finished sample keeps the carried value there), the others
+                # into a buffer that is zero for finished samples.
+                if s > 0 and live is not None:
+                    dh_extra.zero_()
+                ops.dgrad(dy, groups[s][1], dh_state[0] if s == 0 else dh_extra, dx=dxw, dx_channels=cs,
+                          dx_accumulate=s > 0, durations=durations_dev, t=t)
+                if s > 0:
+                    dh0_sum = dh_extra.clone() if dh0_sum is None else dh0_sum + dh_extra
+            if dh0_sum is not None:
+                dh_state[0] += dh0_sum
+            d_x[t] = dxw[..., :C]
+            for s in range(1, k):  # h_prev[16 s:] entered through the joint input
+                g = dxw[..., C + Fh * (s - 1):C + Fh * s]
+                dh_state[s] = (torch.where(live, g, dh_state[s]) if live is not None else g).contiguous()
+        dw_x = torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32)
+        dw_h = torch.zeros_like(cell.hidden_to_state_kernel, dtype=torch.float32)
+        dbias = torch.zeros_like(cell.bias, dtype=torch.float32)
+        for s in range(k):
+            if t_run > 0:
+                ops.wgrad_finish(slabs[s], (B, H, W, cs), C + F - Fh, 0, *gw[s])
+            cols = groups[s][0]
+            dw_x[:, :, :, cols] = gw[s][0][:, :, :C]
+            dw_h[:, :, Fh:, cols] = gw[s][0][:, :, C:]
+            dw_h[:, :, :Fh, cols] = gw[s][1]
+            dbias[cols] = gw[s][2]
+        xd, cd, hd = ctx.in_dtypes
+        ctx.saved = ctx.cell = None
+        return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
+                dw_x, dw_h, dbias)
+
+
+def _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state):
+    """Cells wider than 16 filters: one cell, time-major tensor input, the whole sequence as one autograd node
+    (``_WideSequenceFunction``).  Same masking rule: past a sample's length the output is zero and the state is
+    carried through."""
+    if seq.x_seq is None or len(multi.cells) != 1:
+        raise NotImplementedError("wide cells: a single cell over a time-major tensor input")
+    cell = multi.cells[0]
+    c0, h0 = initial_state[0]
+    args = (cell, durations_dev, t_run, seq.x_seq, c0, h0, cell.input_to_state_kernel, cell.hidden_to_state_kernel,
+            cell.bias)
+    if torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in args):
+        out, c, h = _WideSequenceFunction.apply(*args)
+    else:
+        class _Ctx:  # the forward alone; nothing is kept
+            def set_materialize_grads(self, _):
+                pass
+        out, c, h = _WideSequenceFunction.forward(_Ctx(), *[a.detach() if torch.is_tensor(a) else a for a in args])
+    return out, (LSTMStateTuple(c, h),)
 
 
 def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_major=True, output_pool=1, steps=None):
@@ -593,7 +723,7 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
     if wide:
         if output_pool != 1:
             raise NotImplementedError("output_pool is for 16-filter cells")
-        out, final = _dynamic_rnn_stepwise(multi, seq, durations_dev, t_run, initial_state)
+        out, final = _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state)
         if time_major:
             out = out.transpose(0, 1)
         return out, (final if isinstance(cell, MultiRNNCell) else final[0])

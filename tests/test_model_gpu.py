@@ -49,6 +49,8 @@ def rel_err(got, ref):
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
 
 
+BF16_GRAD_L2, BF16_GRAD_COS = 3e-1, 0.95  # measured worst: 0.23 and 0.973 (EndTokenDeep_2, first encoder kernel)
+
 CASES = [("History2Large", dict()), ("History0", dict()), ("RNNConv", dict()), ("EndTokenDeep_2", dict()),
          ("History1Large", dict())]
 
@@ -105,6 +107,19 @@ def test_bf16_model_tracks_the_oracle(name):
     loss = model.train_step(images, durations, histories, targets)
     assert rel_err(model.prediction_logits.float(), logits_ref) < 5e-2
     assert abs(loss.item() - loss_ref) < 2e-2 * abs(loss_ref)
+    # Gradients (the step leaves them in place).  bf16 activations, weights and carried state gradients through up
+    # to 7 encoder layers, 5 recurrent layers and 10 steps: every variable's gradient keeps its direction (cosine
+    # with the float64 gradient above BF16_GRAD_COS) and its size (relative L2 error below BF16_GRAD_L2); the
+    # deepest tensors (first encoder kernels of the deep net) are the worst.
+    worst_l2, worst_cos = 0.0, 1.0
+    for p, g in zip(model.trainable_variables, _flat_oracle_grads(grads_ref)):
+        got = p.grad.detach().double().cpu().numpy().ravel()
+        ref = np.asarray(g, np.float64).ravel()
+        l2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        cos = float(got @ ref) / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-30)
+        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
+        assert l2 < BF16_GRAD_L2 and cos > BF16_GRAD_COS, (name, tuple(p.shape), l2, cos)
+    print("bf16 gradients of %s: worst relative L2 error %.3e, worst cosine %.5f" % (name, worst_l2, worst_cos))
 
 
 def test_points_and_dense_histories_agree_and_train_reduces_loss():

@@ -17,7 +17,7 @@ def run():
     from imagesegmentation_amd.polyrl import a3c
     from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
     dev = torch.device("cuda:0")
-    n = 256
+    n = int(os.environ.get("ISG_A3C_ENVS", "256"))
     ds = data.PolygonDataset.synthetic(64, image_size=32, prediction_size=32, max_timesteps=10, history_length=2, seed=30)
     rs = np.random.RandomState(40)
     idx = rs.randint(0, len(ds), [n])
