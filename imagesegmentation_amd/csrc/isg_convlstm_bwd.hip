@@ -24,6 +24,24 @@ namespace {
 
 constexpr int kBwdThreads = 512;
 
+// Diagnostic build only (-DISG_STAMPS, tools/stamp_bwd.py): per-phase cycle sums of waves 0 and 7, written to a
+// buffer that nothing else reads.  In the shipped library no stamp executes.
+#ifdef ISG_STAMPS
+__device__ unsigned long long* g_bwd_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long bwd_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define BSTAMP(var) const unsigned long long var = bwd_stamp()
+#define BSTAMP_ADD(slot, a, b) stamp_sum[slot] += (b) - (a)
+#else
+#define BSTAMP(var)
+#define BSTAMP_ADD(slot, a, b)
+#endif
+
 struct BwdParams {
     const void* gates;      // [B,H,W,F,4] post-activation (tanh j, sig i, sig f, sig o)
     const float* c_prev;    // [B,H,W,F]
@@ -66,7 +84,7 @@ struct FB {
     static constexpr int W_BYTES = NS * MT * 1024;
     static constexpr int OFF_DYH = W_BYTES, OFF_DYI = OFF_DYH + DYH_BYTES, OFF_IN = OFF_DYI + DYI_BYTES;
     static constexpr int LDS_BYTES = OFF_IN + IN_BYTES;
-    static constexpr int NPW = (NPXH * 8 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (16 B of gates each)
+    static constexpr int NPW = (NPXH * 4 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (4 channels per item)
     static constexpr int NCH0 = C0 / 8, NCHT = NCH0 + 2;                    // 16-byte chunks of x / of [x | h_prev]
     static constexpr int NXP = (NPXH * NCHT + kBwdThreads - 1) / kBwdThreads;
     static constexpr int NSLOT = MT == 1 ? 3 : 5;        // (tap, row tile) pairs per wave in the weight gradient
@@ -84,7 +102,6 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     using T = __bf16;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     (void)sizeof(s16x8);
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
     char* lds_dyh = smem + K::OFF_DYH;
@@ -117,11 +134,14 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const int n_iter = (tiles_per + wg_per - 1) / wg_per;
 
     // ---- where this thread's items of every pass sit in the halo tile (fixed for the whole kernel) ----
-    const int q = tid & 7;  // gate-backward item = (halo pixel, channel pair q): 512 % 8 == 0 keeps q per thread
+    // gate-backward item = (halo pixel, 4 channels 4 q .. 4 q + 3): 32 bytes of gates, 16 of each cell state, 8 of each
+    // incoming gradient.  (Two channels per item was measured: the per-item bookkeeping then weighs as much as the
+    // gate arithmetic.)  512 % 4 == 0 keeps q per thread.
+    const int q = tid & 3;
     int pinfo[K::NPW];      // hy | hx << 8 | exists << 31
 #pragma unroll
     for (int j = 0; j < K::NPW; ++j) {
-        const int px = j * (kBwdThreads / 8) + (tid >> 3);
+        const int px = j * (kBwdThreads / 4) + (tid >> 2);
         const bool exists = px < K::NPXH;
         const int cpx = exists ? px : K::NPXH - 1;
         const int hy = cpx / HALO_W, hx = cpx - hy * HALO_W;
@@ -142,9 +162,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     static_assert(K::IN_BYTES < (1 << 18), "LDS offsets are packed into 18 bits");
 
     // ---- staged operands of one tile ----
-    uint4 sg[K::NPW];              // gates: 2 channels x 4 gates
-    uint2 scp[K::NPW], scc[K::NPW];  // c_prev, c_cur: 2 floats
-    unsigned sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 2 bf16
+    uint4 sg[K::NPW][2];             // gates: 4 channels x 4 gates
+    uint4 scp[K::NPW], scc[K::NPW];  // c_prev, c_cur: 4 floats
+    uint2 sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 4 bf16
     uint4 sx[K::NXP];
     unsigned pw_inside = 0u, x_inside = 0u;
     int st_dur = 0x7fffffff;
@@ -195,14 +215,15 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const unsigned pix = (unsigned)(cy * p.W + cx);
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
-        sg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 16u));
-        scp[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 8u));
-        scc[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.c_cur) + (size_t)(pixel * 64u + q * 8u));
+        sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
+        sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
+        scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
+        scc[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_cur) + (size_t)(pixel * 64u + q * 16u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
-        sda[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
-                                                    (size_t)(apix * (unsigned)(F_ * 2) + q * 4u));
-        sds[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 4u));
-        sdc[j] = *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 4u));
+        sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
+                                                 (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
+        sds[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 8u));
+        sdc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 8u));
     };
     auto load_x = [&](const Tile& r, auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -263,7 +284,12 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     (std::make_integer_sequence<int, K::NXP>{});
     __syncthreads();
 
+#ifdef ISG_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    BSTAMP(t_begin);
     for (int k = 0; k < n_iter; ++k) {
+        BSTAMP(s0);
         const Tile nxt = tile_ref(k + 1);
         const bool live = cur.valid && (p.durations == nullptr || p.t < __builtin_amdgcn_readfirstlane(st_dur));
         int hp[4];
@@ -299,27 +325,30 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     const bool inside = (cur_pw_inside >> j) & 1u;
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
                     const int gy = cur.ty0 - 1 + hy, gx = cur.tx0 - 1 + hx;
-                    float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const unsigned u_dc = sdc[j], u_dh = sds[j], u_da = sda[j];
-                    float dcp[2] = {bf_lo(u_dc), bf_hi(u_dc)};
+                    float out[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+                    float dcp[4] = {bf_lo(sdc[j].x), bf_hi(sdc[j].x), bf_lo(sdc[j].y), bf_hi(sdc[j].y)};
 #ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
                     if (false) {
 #else
                     if (inside) {
 #endif
-                        const float gv[8] = {bf_lo(sg[j].x), bf_hi(sg[j].x), bf_lo(sg[j].y), bf_hi(sg[j].y),
-                                             bf_lo(sg[j].z), bf_hi(sg[j].z), bf_lo(sg[j].w), bf_hi(sg[j].w)};
-                        const float cpv[2] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y)};
-                        const float ccv[2] = {__uint_as_float(scc[j].x), __uint_as_float(scc[j].y)};
-                        float da[2] = {bf_lo(u_da), bf_hi(u_da)};
-                        da[0] *= inv_pool, da[1] *= inv_pool;
-                        const float dh[2] = {da[0] + bf_lo(u_dh), da[1] + bf_hi(u_dh)};
+                        const unsigned gw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
+                                                sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
+                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
+                                              __uint_as_float(scp[j].w)};
+                        const float ccv[4] = {__uint_as_float(scc[j].x), __uint_as_float(scc[j].y), __uint_as_float(scc[j].z),
+                                              __uint_as_float(scc[j].w)};
+                        const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
+                        const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const float g = gv[4 * c], ig = gv[4 * c + 1], fg = gv[4 * c + 2], og = gv[4 * c + 3];
+                        for (int c = 0; c < 4; ++c) {
+                            const float g = bf_lo(gw[2 * c]), ig = bf_hi(gw[2 * c]), fg = bf_lo(gw[2 * c + 1]), og = bf_hi(gw[2 * c + 1]);
+                            const float dh = da[c] * inv_pool + ds[c];
                             const float tc = act_tanh<true>(ccv[c]);
-                            const float d_o = dh[c] * tc;
-                            const float dct = dcp[c] + dh[c] * og * (1.0f - tc * tc);
+                            const float d_o = dh * tc;
+                            const float dct = dcp[c] + dh * og * (1.0f - tc * tc);
                             out[4 * c] = dct * ig * (1.0f - g * g);
                             out[4 * c + 1] = dct * g * ig * (1.0f - ig);
                             out[4 * c + 2] = dct * cpv[c] * fg * (1.0f - fg);
@@ -327,23 +356,31 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                             dcp[c] = dct * fg;
                         }
                     }
-                    const bf16x8 o = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
-                    *reinterpret_cast<bf16x8*>(lds_dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 16) = o;
-                    if (own)
-                        *reinterpret_cast<bf16x8*>(lds_dyi + (q >> 2) * K::DYI_REGION +
-                                                   ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 3) * 16) = o;
+                    const bf16x8 o0 = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
+                    const bf16x8 o1 = {(T)out[8],  (T)out[9],  (T)out[10], (T)out[11],
+                                       (T)out[12], (T)out[13], (T)out[14], (T)out[15]};
+                    char* dh_dst = lds_dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
+                    *reinterpret_cast<bf16x8*>(dh_dst) = o0;
+                    *reinterpret_cast<bf16x8*>(dh_dst + 16) = o1;
+                    if (own) {
+                        char* di_dst = lds_dyi + (q >> 1) * K::DYI_REGION + ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 1) * 32;
+                        *reinterpret_cast<bf16x8*>(di_dst) = o0;
+                        *reinterpret_cast<bf16x8*>(di_dst + 16) = o1;
+                    }
                     if (own && inside) {
                         const unsigned pixel = (unsigned)((cur.b * p.H + gy) * p.W + gx);
-                        *reinterpret_cast<bf16x2*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 4u)) =
-                            bf16x2{(T)dcp[0], (T)dcp[1]};
+                        *reinterpret_cast<bf16x4*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 8u)) =
+                            bf16x4{(T)dcp[0], (T)dcp[1], (T)dcp[2], (T)dcp[3]};
                         if (p.hist > 0) {
                             // dY at the pixels the history taps reach, kept for the tap weights' gradient
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const int tx = hp[2 * i] - gx + 1, ty = hp[2 * i + 1] - gy + 1;
-                                if (i < p.hist && hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u)
-                                    *reinterpret_cast<bf16x8*>(static_cast<T*>(p.hist_dy) +
-                                                               ((((size_t)cur.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 8) = o;
+                                if (i < p.hist && hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u) {
+                                    T* hd = static_cast<T*>(p.hist_dy) + ((((size_t)cur.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 16;
+                                    *reinterpret_cast<bf16x8*>(hd) = o0;
+                                    *reinterpret_cast<bf16x8*>(hd + 8) = o1;
+                                }
                             }
                         }
                     }
@@ -382,7 +419,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
         }
+        BSTAMP(s1);
         __syncthreads();
+        BSTAMP(s2);
+        BSTAMP_ADD(0, s0, s1);  // phase A (gate backward, LDS writes, issue of the next tile's loads)
+        BSTAMP_ADD(1, s1, s2);  // barrier after phase A
 
         if (live) {
             // ---------------- phase B1: data gradient of this wave's tile row ----------------
@@ -408,6 +449,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
 #endif
+            BSTAMP(s3);
+            BSTAMP_ADD(2, s2, s3);  // data-gradient k-loop
             if (e_in) {
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
@@ -427,6 +470,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
 
+            BSTAMP(s4);
+            BSTAMP_ADD(3, s3, s4);  // data-gradient stores
             // ---------------- phase B2: weight gradient, this wave's taps x column half ----------------
 #ifndef ISG_BWD_NO_WGRAD
             {
@@ -470,10 +515,22 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
 #endif
+            BSTAMP(s5);
+            BSTAMP_ADD(4, s4, s5);  // weight-gradient k-loop
         }
+        BSTAMP(s6);
         __syncthreads();
+        BSTAMP(s7);
+        BSTAMP_ADD(5, s6, s7);  // barrier after phase B
         cur = nxt;
     }
+#ifdef ISG_STAMPS
+    BSTAMP(t_end);
+    stamp_sum[6] = t_end - t_begin;
+    stamp_sum[7] = n_iter;
+    if (g_bwd_stamp_buf != nullptr && lane == 0 && (wave == 0 || wave == 7))
+        for (int i = 0; i < 8; ++i) g_bwd_stamp_buf[(blockIdx.x * 2 + (wave == 7)) * 8 + i] = stamp_sum[i];
+#endif
 
     // ---- this workgroup's partial sums ----
     float* slab = p.slab + (size_t)blockIdx.x * 9 * (MT * 32) * NG;
@@ -549,6 +606,12 @@ bool bwd_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
 }
 
 }  // namespace
+
+#ifdef ISG_STAMPS
+extern "C" int isg_debug_set_bwd_stamp_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
     return bwd_supported(Cs, F, dtype, B, H, W, hist) ? 1 : 0;
