@@ -598,8 +598,14 @@ class _WideSequenceFunction(torch.autograd.Function):
         T = d_out.shape[1] if d_out is not None else t_run
         part = lambda g, s, d: (g[..., Fh * s:Fh * s + Fh].to(d).contiguous() if g is not None else
                                 torch.zeros([B, H, W, Fh], dtype=d, device=dev))
-        dc_state = [part(d_c, s, torch.float32) for s in range(k)]
+        # one launch per (step, group) where the fused backward step exists for the groups' shape (its carried
+        # cell-state gradient is in the compute type and ping-pongs between two buffers), else three
+        fused = t_run > 0 and ops.bwd_fused_supported(groups[0][1], B, H, W)
+        dc_state = [part(d_c, s, dt if fused else torch.float32) for s in range(k)]
         dh_state = [part(d_h, s, dt) for s in range(k)]
+        if fused:
+            dc_next = [torch.empty_like(g) for g in dc_state]
+            dh_next0 = torch.empty_like(dh_state[0])
         if d_out is not None:  # group-major, one copy for the whole sequence
             d_out_g = d_out.to(dt).reshape(B, T, H, W, k, Fh).permute(4, 0, 1, 2, 3, 5).contiguous()
         else:
@@ -617,6 +623,19 @@ class _WideSequenceFunction(torch.autograd.Function):
             mode = ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST
             dh0_sum = None
             for s in range(k):
+                if fused:
+                    # the recurrent input of every group is group 0's h: group 0's gradient of it becomes the carried
+                    # one (a finished sample keeps its carried value), the other groups' are added to it below
+                    ops.bwd_fused(Gs[s][t], Cs[s][t], Cs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
+                                  dc_state[s], xw[t], Hs[0][t], groups[s][1], dc_next[s], dh_next0 if s == 0 else dh_extra,
+                                  slabs[s], mode, None, dx=dxw, dx_channels=cs, dx_accumulate=s > 0,
+                                  durations=durations_dev, t=t)
+                    dc_state[s], dc_next[s] = dc_next[s], dc_state[s]
+                    if s > 0:
+                        # (for a finished sample the kernel passes the group's OWN carried gradient through)
+                        extra = dh_extra.clone() if live is None else torch.where(live, dh_extra, torch.zeros_like(dh_extra))
+                        dh0_sum = extra if dh0_sum is None else dh0_sum + extra
+                    continue
                 ops.pointwise_bwd(Gs[s][t], Cs[s][t], Cs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s], dc_state[s],
                                   durations_dev, t, dy=dy, dc_prev=dc_state[s])
                 ops.wgrad(xw[t], Hs[0][t], dy, C + F - Fh, gw[s][0], gw[s][1], gw[s][2], True, durations_dev, t, mode=mode,
@@ -630,6 +649,8 @@ class _WideSequenceFunction(torch.autograd.Function):
                           dx_accumulate=s > 0, durations=durations_dev, t=t)
                 if s > 0:
                     dh0_sum = dh_extra.clone() if dh0_sum is None else dh0_sum + dh_extra
+            if fused:
+                dh_state[0], dh_next0 = dh_next0, dh_state[0]
             if dh0_sum is not None:
                 dh_state[0] += dh0_sum
             d_x[t] = dxw[..., :C]

@@ -89,7 +89,7 @@ struct FB {
     static constexpr int NXP = (NPXH * NCHT + kBwdThreads - 1) / kBwdThreads;
     static constexpr int NSLOT = MT == 1 ? 3 : 5;        // (tap, row tile) pairs per wave in the weight gradient
     static_assert(TR * MT == 8, "one data-gradient unit (tile row x row tile) per wave");
-    static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0 && C0 <= 32, "input channels must fit the row tiles");
+    static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0, "input channels must fit the row tiles");
     static_assert(DYH_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -601,7 +601,7 @@ int bwd_num_cus() {
 }
 
 bool bwd_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
-    return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32) && hist >= 0 && hist <= 2 && B >= 1 && H >= 1 && W >= 1 &&
+    return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32 || Cs == 48) && hist >= 0 && hist <= 2 && B >= 1 && H >= 1 && W >= 1 &&
            (long long)B * H * W * 128 < (1LL << 32);
 }
 
@@ -630,7 +630,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
                                       int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
                                       void* stream) {
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
-                "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16 or 32, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
+                "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
     ISG_REQUIRE(gates && c_prev && c_cur && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
                     dh_state && dc_state, ISG_EINVAL, "isg_convlstm_bwd_fused: null pointer");
@@ -667,7 +667,9 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
         hipError_t e = hipMemsetAsync(hist_scratch, 0, (size_t)isg_convlstm_bwd_fused_hist_bytes(B, hist), s);
         ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    int rc = Cs == 16 ? launch_bwd<16, 1, 8>(p, bwd_num_cus(), s) : launch_bwd<32, 2, 4>(p, bwd_num_cus(), s);
+    int rc = Cs == 16   ? launch_bwd<16, 1, 8>(p, bwd_num_cus(), s)
+             : Cs == 32 ? launch_bwd<32, 2, 4>(p, bwd_num_cus(), s)
+                        : launch_bwd<48, 2, 4>(p, bwd_num_cus(), s);
     if (rc != ISG_OK) return rc;
     if (hist > 0) {
         hipLaunchKernelGGL(hist_side_wgrad_kernel, dim3(9 * hist), dim3(256), 0, s, static_cast<const __bf16*>(hist_scratch), B,

@@ -51,8 +51,9 @@ __device__ __forceinline__ int scalar_load(const int* base, long long index) {
         (const __attribute__((address_space(4))) char*)(unsigned long long)(base) + i * 4);
 }
 
-// NPT = tile rows per wave: 2 -> the 8 x 32 tile every kernel uses; 1 -> a 4 x 32 tile, whose smaller halo
-// image leaves LDS room for a two-row-tile weight image (the 48-row data gradient of layer 0 in ONE launch)
+// NPT = tile rows per wave: 2 -> the 8 x 32 tile; 1 -> a 4 x 32 tile, whose smaller halo image leaves LDS room
+// for a two-row-tile weight image over 64 staged channels (the 48-row data gradient of layer 0 in ONE launch; the
+// forward cell on a 48-channel input, which has no pooled output: the pool's reduction goes by 8-row tiles)
 template <int C0, int C1, int MT, int MODE, int NPT = 2>
 struct PP {
     static constexpr int TH_ = 4 * NPT;
@@ -86,7 +87,6 @@ struct PP {
 template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
 __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     using K = PP<C0, C1, MT, MODE, NPT>;
-    static_assert(NPT == 2 || MODE == 1, "the 4-row tile is for the data gradient");
     using T = __bf16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     auto epilogue = [&](const TileRef& r) {
         if (!r.valid) return;
         if (!r.live) {
-            if constexpr (MODE == 0) lstm_copy_through_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256);
+            if constexpr (MODE == 0) lstm_copy_through_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             return;
         }
@@ -529,6 +529,7 @@ int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     using K = PP<C0, C1, MT, MODE, NPT>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
     if (MODE == 0 && p0.hist > 2) return kNotSupported;
+    if (MODE == 0 && NPT != 2 && p0.pool_out != nullptr) return kNotSupported;
     // the staging loads address their arrays with 32-bit byte offsets
     if ((long long)p0.B * p0.H * p0.W * (C0 > C1 ? C0 : C1) * 2 >= (1LL << 32)) return kNotSupported;
     ConvParams p = p0;
@@ -890,6 +891,7 @@ int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream
     if (mode == 0) {
         if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, false>(p, num_cus, stream);
         if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, false>(p, num_cus, stream);
+        if (p.c0 == 48 && p.c1 == 16) return launch_pp<48, 16, 2, 0, false, 1>(p, num_cus, stream);
         return kNotSupported;
     }
     if (p.c0 == NG && p.c1 == 0 && mt == 1) return launch_pp<NG, 0, 1, 1, false>(p, num_cus, stream);

@@ -228,8 +228,8 @@ __device__ __forceinline__ void lstm_finish_pixel(const ConvParams& p, int b, in
 // emitted output is zero.  Called by `nthreads` threads with ids 0..nthreads-1.
 template <typename T>
 __device__ __forceinline__ void lstm_copy_through_tile(const ConvParams& p, int b, int ty0, int tx0, int tid,
-                                                       int nthreads) {
-    for (int i = tid; i < TH * TW * (F_ / 4); i += nthreads) {
+                                                       int nthreads, int tile_rows = TH) {
+    for (int i = tid; i < tile_rows * TW * (F_ / 4); i += nthreads) {
         const int q4 = i & 3, pix = i >> 2;
         const int gy = ty0 + pix / TW, gx = tx0 + (pix & (TW - 1));
         if (gy < p.H && gx < p.W) {

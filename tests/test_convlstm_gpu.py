@@ -542,3 +542,55 @@ def test_fused_backward_step_matches_the_three_kernel_backward(case, monkeypatch
         err = float((got[key] - ref[key]).abs().max()) / scale
         assert err <= 1e-2, "%s: fused backward differs from the three-kernel backward by %.3e of max" % (key, err)
         assert torch.isfinite(got[key]).all()
+
+
+def test_wide_cell_fused_backward_matches_the_three_kernel_backward(monkeypatch):
+    """The 32-filter cell's groups (48 joint input channels) through the one-launch backward step against the
+    pointwise / dgrad / wgrad sequence: every gradient, bf16, partial tiles, a finished and an empty sample."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell, dynamic_rnn
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(37)
+    T, B, H, W, C, F = 4, 4, 21, 38, 32, 32
+    w_x, w_h, bias = rand_cell(rs, C, F=F)
+    cell = ConvLSTMCell(shape=[H, W], filters=F, kernel=[3, 3], compute_dtype=dtype, device=dev())
+    cell.build(C, dev())
+    with torch.no_grad():
+        cell.input_to_state_kernel.copy_(torch.tensor(w_x))
+        cell.hidden_to_state_kernel.copy_(torch.tensor(w_h))
+        cell.bias.copy_(torch.tensor(bias))
+    t = lambda a, d=torch.float32: torch.tensor(a, dtype=d, device=dev())
+    x = rs.randn(T, B, H, W, C)
+    durations = np.array([T, 0, 2, 3], np.int32)
+    init = (rs.randn(B, H, W, F) * 0.3, rs.randn(B, H, W, F) * 0.3)
+    d_out, d_c, d_h = rs.randn(T, B, H, W, F), rs.randn(B, H, W, F), rs.randn(B, H, W, F)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("ISG_NO_FUSED_BWD", raising=False)
+        else:
+            monkeypatch.setenv("ISG_NO_FUSED_BWD", "1")
+        for prm in (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias):
+            prm.grad = None
+        tx = t(x, dtype).requires_grad_(True)
+        tc, th = t(init[0]).requires_grad_(True), t(init[1], dtype).requires_grad_(True)
+        out, final = dynamic_rnn(cell, tx, sequence_length=durations, initial_state=(tc, th), time_major=True)
+        loss = (out.float() * t(d_out)).sum() + (final.c * t(d_c)).sum() + (final.h.float() * t(d_h)).sum()
+        calls = []
+        real = ops.bwd_fused
+        monkeypatch.setattr(ops, "bwd_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        loss.backward()
+        monkeypatch.setattr(ops, "bwd_fused", real)
+        got = dict(x=tx.grad.float().clone(), c0=tc.grad.clone(), h0=th.grad.float().clone(),
+                   w_x=cell.input_to_state_kernel.grad.clone(), w_h=cell.hidden_to_state_kernel.grad.clone(),
+                   b=cell.bias.grad.clone(), out=out.float().detach().clone())
+        return got, len(calls)
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 2 * int(durations.max())
+    for key in ref:
+        scale = max(float(ref[key].abs().max()), 1e-6)
+        err = float((got[key] - ref[key]).abs().max()) / scale
+        assert err <= 1e-2, "%s: fused backward differs from the three-kernel backward by %.3e of max" % (key, err)
+        assert torch.isfinite(got[key]).all()
