@@ -75,14 +75,13 @@ struct FB {
     static constexpr int NPXH = (TR + 2) * HALO_W;       // halo tile pixels
     static constexpr int DY_PSTRIDE = NG * 2 + 16;       // padded pixel stride of the halo dY image
     static constexpr int DYH_BYTES = NPXH * DY_PSTRIDE;
-    static constexpr int RSTRIDE = 64;                   // 32 channels: one region row
-    static constexpr int DYI_REGION = TR * TW * RSTRIDE + 128;
-    static constexpr int DYI_BYTES = 2 * DYI_REGION;
+    static constexpr int RSTRIDE = 64;                   // 32 channels: one region row of the [x | h_prev] image
     static constexpr int IN_REGION = NPXH * RSTRIDE;
     static constexpr int IN_BYTES = MT * IN_REGION;
     static constexpr int NS = 9 * (NG / 16);             // k-steps of the data gradient
     static constexpr int W_BYTES = NS * MT * 1024;
-    static constexpr int OFF_DYH = W_BYTES, OFF_DYI = OFF_DYH + DYH_BYTES, OFF_IN = OFF_DYI + DYI_BYTES;
+    // two dY images: the gate backward of the next tile fills one while phase B reads the other
+    static constexpr int OFF_DYH = W_BYTES, OFF_IN = OFF_DYH + 2 * DYH_BYTES;
     static constexpr int LDS_BYTES = OFF_IN + IN_BYTES;
     static constexpr int NPW = (NPXH * 4 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (4 channels per item)
     static constexpr int NCH0 = C0 / 8, NCHT = NCH0 + 2;                    // 16-byte chunks of x / of [x | h_prev]
@@ -105,7 +104,6 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
     char* lds_dyh = smem + K::OFF_DYH;
-    char* lds_dyi = smem + K::OFF_DYI;
     char* lds_in = smem + K::OFF_IN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,9 +122,12 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ntiles = tiles_per_img * p.B;
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 labels the workgroups that share an L2).  Each
-    // label sweeps its own contiguous eighth of the tiles, its workgroups side by side: a tile's halo is then
-    // re-read by workgroups on the same L2 at about the same time, not fetched once per XCD.  (Speed only: the
-    // result does not depend on which workgroup takes which tile.)
+    // label sweeps its own contiguous eighth of the tiles, its workgroups side by side along the image rows: a
+    // tile's halo is then re-read by workgroups on the same L2 at about the same time, and the workgroups of a
+    // label read neighbouring addresses.  (Measured against runs of vertically adjacent tiles per workgroup, which
+    // re-read the shared halo rows from the same CU: 3 - 14 % slower, growing with the run length - 256 separate
+    // streams cost more in the memory system than the halo hits save.  Speed only: the result does not depend on
+    // which workgroup takes which tile.)
     const bool by_xcd = ((int)gridDim.x & 7) == 0;
     const int wg_per = by_xcd ? (int)gridDim.x >> 3 : (int)gridDim.x;       // workgroups per label
     const int tiles_per = by_xcd ? (ntiles + 7) >> 3 : ntiles;              // tiles per label
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const int hp_last = p.hist > 0 ? 2 * p.hist - 1 : 0;
 
     auto load_meta = [&](const Tile& r) {
-        pw_inside = 0u, x_inside = 0u;
         st_dur = dur_base[r.b * dur_mul];
 #pragma unroll
         for (int i = 0; i < 4; ++i) st_hp[i] = hp_base[(size_t)r.b * hp_bstride + min(i, hp_last)];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int li = lane & 15, g16 = lane >> 4;
         const int csub = 16 * (g16 & 1) + 4 * (li & 3);      // channel offset inside the 32-channel region
         const int lane_px = 8 * half + (li >> 2);            // pixel inside the 16-pixel k-step (second read: + 4)
-        wg_dy = lds_dyi + wg_n * K::DYI_REGION + lane_px * K::RSTRIDE + csub * 2;
+        wg_dy = lds_dyh + (HALO_W + 1 + lane_px) * K::DY_PSTRIDE + wg_n * 64 + csub * 2;
 #pragma unroll
         for (int i = 0; i < K::NSLOT; ++i) {
             const int pair = wg_first + min(i, wg_cnt - 1);
@@ -276,55 +276,35 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     // data-gradient unit of this wave
     const int dg_row = MT == 1 ? wave : wave >> 1, dg_mt = MT == 1 ? 0 : wave & 1;
 
-    Tile cur = tile_ref(0);
-    load_meta(cur);
-    [&]<int... I>(std::integer_sequence<int, I...>) { (load_pw(cur, std::integral_constant<int, I>{}), ...); }
-    (std::make_integer_sequence<int, K::NPW>{});
-    [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(cur, std::integral_constant<int, I>{}), ...); }
-    (std::make_integer_sequence<int, K::NXP>{});
-    __syncthreads();
+    // ---------------- the tile pipeline ----------------
+    // Three tiles are in flight.  Between two workgroup barriers a wave
+    //   - runs phase B of tile n out of dY image n % 2 and the [x | h_prev] image (matrix pipe), and
+    //   - turns the staged operands of tile n + 1 into dY image (n + 1) % 2 (vector ALU; dc_prev leaves for
+    //     global memory), requesting the operands of tile n + 2 into each staging register as it is freed.
+    // Neither touches what the other reads, so their order inside the interval is free: waves 0-3 (one per SIMD)
+    // take the gate backward first, waves 4-7 phase B first, and on every SIMD one wave's vector arithmetic runs
+    // under the other's MFMAs.  A short store phase after the closing barrier writes the [x | h_prev] tile of
+    // tile n + 1 (in registers since the interval before) over that of tile n.
+    bool m_live = false;     // facts of the tile the last gate backward worked on, taken from the staging words
+    int m_hp[4] = {-1, 0, -1, 0};
 
-#ifdef ISG_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    BSTAMP(t_begin);
-    for (int k = 0; k < n_iter; ++k) {
-        BSTAMP(s0);
-        const Tile nxt = tile_ref(k + 1);
-        const bool live = cur.valid && (p.durations == nullptr || p.t < __builtin_amdgcn_readfirstlane(st_dur));
-        int hp[4];
+    auto gate_backward = [&](const Tile& c, const Tile& req, char* dyh) __attribute__((always_inline)) {
+        m_live = c.valid && (p.durations == nullptr || p.t < __builtin_amdgcn_readfirstlane(st_dur));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hp[i] = __builtin_amdgcn_readfirstlane(st_hp[i]);
-        const unsigned cur_pw_inside = pw_inside, cur_x_inside = x_inside;
-
-        // the running dx sum this wave's epilogue adds to: requested before anything of the next tile, so that
-        // waiting for it does not wait for the prefetch behind it
-        uint2 pre[4];
-        const int egy = cur.ty0 + dg_row, egx = cur.tx0 + px_l;
-        const bool e_in = cur.valid && egy < p.H && egx < p.W;
-        const size_t epixel = (size_t)(unsigned)((cur.b * p.H + min(egy, p.H - 1)) * p.W + min(egx, p.W - 1));
-        if (live && p.dx && p.dx_accumulate) {
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
-                pre[a4] = make_uint2(0u, 0u);
-                if (cc0 < C0 && cc0 < p.dx_channels)
-                    pre[a4] = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.dx) + epixel * p.dx_cstride + cc0);
-            }
-        }
-
-        // ---------------- phase A: dY of the halo tile into LDS, dc_prev, the [x | h_prev] image ----------------
-        load_meta(nxt);  // (after this tile's facts were taken out of the staging words above)
+        for (int i = 0; i < 4; ++i) m_hp[i] = __builtin_amdgcn_readfirstlane(st_hp[i]);
+        const unsigned inside_bits = pw_inside;
+        pw_inside = 0u;
+        load_meta(req);
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 constexpr int j = I;
                 int inf = pinfo[j];
                 asm volatile("" : "+v"(inf));
-                if (live && inf < 0) {
+                if (m_live && inf < 0) {
                     const int hy = inf & 0xff, hx = (inf >> 8) & 0xff;
-                    const bool inside = (cur_pw_inside >> j) & 1u;
+                    const bool inside = (inside_bits >> j) & 1u;
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
-                    const int gy = cur.ty0 - 1 + hy, gx = cur.tx0 - 1 + hx;
+                    const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
                     float out[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) out[i] = 0.0f;
@@ -343,41 +323,37 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
                         const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float g = bf_lo(gw[2 * c]), ig = bf_hi(gw[2 * c]), fg = bf_lo(gw[2 * c + 1]), og = bf_hi(gw[2 * c + 1]);
-                            const float dh = da[c] * inv_pool + ds[c];
-                            const float tc = act_tanh<true>(ccv[c]);
+                        for (int ch = 0; ch < 4; ++ch) {
+                            const float g = bf_lo(gw[2 * ch]), ig = bf_hi(gw[2 * ch]);
+                            const float fg = bf_lo(gw[2 * ch + 1]), og = bf_hi(gw[2 * ch + 1]);
+                            const float dh = da[ch] * inv_pool + ds[ch];
+                            const float tc = act_tanh<true>(ccv[ch]);
                             const float d_o = dh * tc;
-                            const float dct = dcp[c] + dh * og * (1.0f - tc * tc);
-                            out[4 * c] = dct * ig * (1.0f - g * g);
-                            out[4 * c + 1] = dct * g * ig * (1.0f - ig);
-                            out[4 * c + 2] = dct * cpv[c] * fg * (1.0f - fg);
-                            out[4 * c + 3] = d_o * og * (1.0f - og);
-                            dcp[c] = dct * fg;
+                            const float dct = dcp[ch] + dh * og * (1.0f - tc * tc);
+                            out[4 * ch] = dct * ig * (1.0f - g * g);
+                            out[4 * ch + 1] = dct * g * ig * (1.0f - ig);
+                            out[4 * ch + 2] = dct * cpv[ch] * fg * (1.0f - fg);
+                            out[4 * ch + 3] = d_o * og * (1.0f - og);
+                            dcp[ch] = dct * fg;
                         }
                     }
                     const bf16x8 o0 = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
                     const bf16x8 o1 = {(T)out[8],  (T)out[9],  (T)out[10], (T)out[11],
                                        (T)out[12], (T)out[13], (T)out[14], (T)out[15]};
-                    char* dh_dst = lds_dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
+                    char* dh_dst = dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
                     *reinterpret_cast<bf16x8*>(dh_dst) = o0;
                     *reinterpret_cast<bf16x8*>(dh_dst + 16) = o1;
-                    if (own) {
-                        char* di_dst = lds_dyi + (q >> 1) * K::DYI_REGION + ((hy - 1) * TW + (hx - 1)) * K::RSTRIDE + (q & 1) * 32;
-                        *reinterpret_cast<bf16x8*>(di_dst) = o0;
-                        *reinterpret_cast<bf16x8*>(di_dst + 16) = o1;
-                    }
                     if (own && inside) {
-                        const unsigned pixel = (unsigned)((cur.b * p.H + gy) * p.W + gx);
+                        const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
                         *reinterpret_cast<bf16x4*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 8u)) =
                             bf16x4{(T)dcp[0], (T)dcp[1], (T)dcp[2], (T)dcp[3]};
                         if (p.hist > 0) {
                             // dY at the pixels the history taps reach, kept for the tap weights' gradient
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
-                                const int tx = hp[2 * i] - gx + 1, ty = hp[2 * i + 1] - gy + 1;
-                                if (i < p.hist && hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u) {
-                                    T* hd = static_cast<T*>(p.hist_dy) + ((((size_t)cur.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 16;
+                                const int tx = m_hp[2 * i] - gx + 1, ty = m_hp[2 * i + 1] - gy + 1;
+                                if (i < p.hist && m_hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u) {
+                                    T* hd = static_cast<T*>(p.hist_dy) + ((((size_t)c.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 16;
                                     *reinterpret_cast<bf16x8*>(hd) = o0;
                                     *reinterpret_cast<bf16x8*>(hd + 8) = o1;
                                 }
@@ -385,144 +361,217 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         }
                     }
                 }
-                load_pw(nxt, std::integral_constant<int, j>{});
+                load_pw(req, std::integral_constant<int, j>{});
             }(), ...);
         }(std::make_integer_sequence<int, K::NPW>{});
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ([&] {
-                constexpr int j = I;
-                int inf = xinfo[j];
-                asm volatile("" : "+v"(inf));
-                if (live && inf < 0) {
-                    const bool inside = (cur_x_inside >> j) & 1u;
-                    *reinterpret_cast<uint4*>(lds_in + (inf & 0x3ffff)) = inside ? sx[j] : make_uint4(0u, 0u, 0u, 0u);
-                }
-                load_x(nxt, std::integral_constant<int, j>{});
-            }(), ...);
-        }(std::make_integer_sequence<int, K::NXP>{});
-        if (cur.valid && !live) {
+    };
+
+    // Store phase of tile `c`: its [x | h_prev] chunks (in sx) into the LDS image, then the request for those of
+    // the tile after it.
+    auto store_phase = [&](const Tile& c, bool live, const Tile& after) __attribute__((always_inline)) {
+        if (live) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ([&] {
+                    constexpr int j = I;
+                    int inf = xinfo[j];
+                    asm volatile("" : "+v"(inf));
+                    if (inf < 0) {
+                        const bool inside = (x_inside >> j) & 1u;
+                        *reinterpret_cast<uint4*>(lds_in + (inf & 0x3ffff)) = inside ? sx[j] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, K::NXP>{});
+        } else if (c.valid) {
             // A masked sample (t >= its length): the state gradients pass through as copies and dx is zero.  Rare,
             // so it reads what it needs itself instead of widening the staged path above.
             for (int i = tid; i < TR * TW * 8; i += kBwdThreads) {
                 const int pix = i >> 3, qq = i & 7;
-                const int gy = cur.ty0 + pix / TW, gx = cur.tx0 + (pix & (TW - 1));
+                const int gy = c.ty0 + pix / TW, gx = c.tx0 + (pix & (TW - 1));
                 if (gy < p.H && gx < p.W) {
-                    const unsigned pixel = (unsigned)((cur.b * p.H + gy) * p.W + gx);
+                    const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
                     const size_t so = (size_t)(pixel * 32u + qq * 4u);
                     *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
                         *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
                     *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
                         *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
                     if (p.dx && !p.dx_accumulate)
-                        for (int c = 2 * qq; c < p.dx_channels; c += 16)
-                            *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + (size_t)pixel * p.dx_cstride + c) = 0u;
+                        for (int ch = 2 * qq; ch < p.dx_channels; ch += 16)
+                            *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + (size_t)pixel * p.dx_cstride + ch) = 0u;
                 }
             }
         }
-        BSTAMP(s1);
-        __syncthreads();
+        x_inside = 0u;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(after, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, K::NXP>{});
+    };
+
+#ifdef ISG_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    // phase B of tile `c`: data gradient of this wave's tile row (+ its stores), then the weight gradient
+    auto phase_b = [&](int dyo, bool e_in, unsigned epixel_u) __attribute__((always_inline)) {
         BSTAMP(s2);
-        BSTAMP_ADD(0, s0, s1);  // phase A (gate backward, LDS writes, issue of the next tile's loads)
-        BSTAMP_ADD(1, s1, s2);  // barrier after phase A
-
-        if (live) {
-            // ---------------- phase B1: data gradient of this wave's tile row ----------------
-            f32x16 acc;
+        // (32-bit byte offsets from the tensors' bases, as everywhere in this kernel: the bases then stay in scalar
+        // registers instead of vector register pairs)
+        const unsigned dx_off = epixel_u * (unsigned)(p.dx_cstride * 2);
+        // the running dx sum the epilogue adds to, requested ahead of the k-loop
+        uint2 pre[4];
+        if (p.dx && p.dx_accumulate) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#ifndef ISG_BWD_NO_DGRAD  // diagnostic builds leave a phase out to see what the others take
-            {
-                const char* bb = lds_dyh + (dg_row * HALO_W + px_l) * K::DY_PSTRIDE + half * 16;
-                const char* aw = lds_w + (size_t)dg_mt * K::NS * 1024 + lane * 16;
-                bf16x8 a[2], b[2];
-                auto fetch = [&](int s, int slot) {
-                    const int tap = s >> 2, qk = s & 3;
-                    a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
-                    b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int s = 0; s < K::NS; ++s) {
-                    if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
+                pre[a4] = make_uint2(0u, 0u);
+                if (cc0 < C0 && cc0 < p.dx_channels)
+                    pre[a4] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2)));
             }
-#endif
-            BSTAMP(s3);
-            BSTAMP_ADD(2, s2, s3);  // data-gradient k-loop
-            if (e_in) {
-#pragma unroll
-                for (int a4 = 0; a4 < 4; ++a4) {
-                    float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
-                    const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
-                    if (cc0 < C0) {
-                        if (p.dx && cc0 < p.dx_channels) {
-                            if (p.dx_accumulate) {
-                                v[0] += bf_lo(pre[a4].x), v[1] += bf_hi(pre[a4].x);
-                                v[2] += bf_lo(pre[a4].y), v[3] += bf_hi(pre[a4].y);
-                            }
-                            store4(static_cast<T*>(p.dx) + epixel * p.dx_cstride + cc0, v);
-                        }
-                    } else if (cc0 < C0 + F_) {
-                        store4(static_cast<T*>(p.dh_prev) + epixel * F_ + (cc0 - C0), v);
-                    }
-                }
-            }
-
-            BSTAMP(s4);
-            BSTAMP_ADD(3, s3, s4);  // data-gradient stores
-            // ---------------- phase B2: weight gradient, this wave's taps x column half ----------------
-#ifndef ISG_BWD_NO_WGRAD
-            {
-                // k-step = 16 consecutive pixels of a tile row.  Both operands come out of pixel-major LDS images
-                // through the transposing read; every address is this lane's fixed base plus a compile-time
-                // offset, and the fragments of the next k-step are requested before this one's MFMAs.
-                constexpr int NBUF = MT == 1 ? 2 : 1;  // the two-row-tile kernel has no registers for a second set
-                bf16x8 bq[NBUF], aq[NBUF][K::NSLOT];
-                auto tr_pair = [](const char* a0) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * K::RSTRIDE));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    return __builtin_bit_cast(bf16x8, both);
-                };
-                auto fetch = [&](int ks, int slot) {
-                    const int r = ks >> 1, x0 = 16 * (ks & 1);
-                    bq[slot] = tr_pair(wg_dy + (r * TW + x0) * K::RSTRIDE);
-#pragma unroll
-                    for (int i = 0; i < K::NSLOT; ++i)
-                        if (i < K::NSLOT - 1 || wg_full) aq[slot][i] = tr_pair(wg_in[i] + (r * HALO_W + x0) * K::RSTRIDE);
-                };
-                if constexpr (NBUF == 2) fetch(0, 0);
-#pragma unroll
-                for (int ks = 0; ks < 2 * TR; ++ks) {
-                    const int cs = NBUF == 2 ? ks & 1 : 0;
-                    if constexpr (NBUF == 2) {
-                        if (ks + 1 < 2 * TR) fetch(ks + 1, cs ^ 1);
-                    } else {
-                        fetch(ks, 0);
-                    }
-                    if (wg_grp == 0) {
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) bsum += (float)bq[cs][jj];
-                    }
-#pragma unroll
-                    for (int i = 0; i < K::NSLOT; ++i)
-                        if (i < K::NSLOT - 1 || wg_full)
-                            wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cs][i], bq[cs], wacc[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#endif
-            BSTAMP(s5);
-            BSTAMP_ADD(4, s4, s5);  // weight-gradient k-loop
         }
+        // (the weight gradient first: what the data gradient's epilogue waits for - the old dx values, and with
+        // them every load requested before them - then has the whole of phase B to arrive)
+#ifndef ISG_BWD_NO_WGRAD
+        {
+            // k-step = 16 consecutive pixels of a tile row.  Both operands come out of pixel-major LDS images
+            // through the transposing read; every address is this lane's fixed base plus a compile-time
+            // offset, and the fragments of the next k-step are requested before this one's MFMAs.
+            constexpr int NBUF = MT == 1 ? 2 : 1;  // the two-row-tile kernel has no registers for a second set
+            bf16x8 bq[NBUF], aq[NBUF][K::NSLOT];
+            auto tr_pair = [](const char* a0, auto stride) {  // 8 consecutive pixels of one k-step half
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * decltype(stride)::value));
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(bf16x8, both);
+            };
+            const char* dyb = wg_dy + dyo;
+            auto fetch = [&](int ks, int slot) {
+                const int r = ks >> 1, x0 = 16 * (ks & 1);
+                bq[slot] = tr_pair(dyb + (r * HALO_W + x0) * K::DY_PSTRIDE, std::integral_constant<int, K::DY_PSTRIDE>{});
+#pragma unroll
+                for (int i = 0; i < K::NSLOT; ++i)
+                    if (i < K::NSLOT - 1 || wg_full)
+                        aq[slot][i] = tr_pair(wg_in[i] + (r * HALO_W + x0) * K::RSTRIDE, std::integral_constant<int, K::RSTRIDE>{});
+            };
+            if constexpr (NBUF == 2) fetch(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2 * TR; ++ks) {
+                const int cs = NBUF == 2 ? ks & 1 : 0;
+                if constexpr (NBUF == 2) {
+                    if (ks + 1 < 2 * TR) fetch(ks + 1, cs ^ 1);
+                } else {
+                    fetch(ks, 0);
+                }
+                if (wg_grp == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) bsum += (float)bq[cs][jj];
+                }
+#pragma unroll
+                for (int i = 0; i < K::NSLOT; ++i)
+                    if (i < K::NSLOT - 1 || wg_full)
+                        wacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cs][i], bq[cs], wacc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+        BSTAMP(s4);
+        BSTAMP_ADD(4, s2, s4);  // weight-gradient k-loop
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#ifndef ISG_BWD_NO_DGRAD  // diagnostic builds leave a phase out to see what the others take
+        {
+            const char* bb = lds_dyh + dyo + (dg_row * HALO_W + px_l) * K::DY_PSTRIDE + half * 16;
+            const char* aw = lds_w + (size_t)dg_mt * K::NS * 1024 + lane * 16;
+            bf16x8 a[2], b[2];
+            auto fetch = [&](int s, int slot) {
+                const int tap = s >> 2, qk = s & 3;
+                a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
+                b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < K::NS; ++s) {
+                if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+        if (e_in) {
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
+                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
+                if (cc0 < C0) {
+                    if (p.dx && cc0 < p.dx_channels) {
+                        if (p.dx_accumulate) {
+                            v[0] += bf_lo(pre[a4].x), v[1] += bf_hi(pre[a4].x);
+                            v[2] += bf_lo(pre[a4].y), v[3] += bf_hi(pre[a4].y);
+                        }
+                        store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
+                    }
+                } else if (cc0 < C0 + F_) {
+                    store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)((cc0 - C0) * 2))), v);
+                }
+            }
+        }
+        BSTAMP(s5);
+        BSTAMP_ADD(3, s4, s5);  // data gradient: k-loop and stores
+    };
+
+    Tile cur = tile_ref(0), nxt = tile_ref(1);
+    load_meta(cur);
+    [&]<int... I>(std::integer_sequence<int, I...>) { (load_pw(cur, std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, K::NPW>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(cur, std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, K::NXP>{});
+    gate_backward(cur, nxt, lds_dyh);  // dY image 0 of tile 0; the operands of tile 1 requested
+    bool cur_live = m_live;
+    int cur_buf = 0;                // dY image of tile `cur`
+    const bool m_first = wave < 4;  // one wave of each kind per SIMD (waves w and w + 4 share one)
+
+    // The join between two intervals: every wave is done with the LDS images of tile `cur`; the next tile
+    // becomes `cur`, its [x | h_prev] chunks go to LDS and those of the tile after it are requested.
+    Tile nxt2 = nxt;
+    auto join = [&]() __attribute__((always_inline)) {
         BSTAMP(s6);
         __syncthreads();
         BSTAMP(s7);
-        BSTAMP_ADD(5, s6, s7);  // barrier after phase B
-        cur = nxt;
+        cur = nxt, nxt = nxt2, cur_live = m_live, cur_buf ^= 1;
+        store_phase(cur, cur_live, nxt);
+        BSTAMP(s8);
+        __syncthreads();
+        BSTAMP(s9);
+        BSTAMP_ADD(5, s6, s7);  // barrier after phase B / the gate backward
+        BSTAMP_ADD(0, s7, s8);  // store phase
+        BSTAMP_ADD(1, s8, s9);  // barrier after it
+    };
+    auto run_b = [&]() __attribute__((always_inline)) {
+        if (cur_live) {
+            const int egy = cur.ty0 + dg_row, egx = cur.tx0 + px_l;
+            const bool e_in = egy < p.H && egx < p.W;
+            const unsigned epixel = (unsigned)((cur.b * p.H + min(egy, p.H - 1)) * p.W + min(egx, p.W - 1));
+            phase_b(cur_buf * K::DYH_BYTES, e_in, epixel);
+        }
+    };
+
+    BSTAMP(t_begin);
+    // Both orders out of ONE copy of each phase (two copies cost more registers than there are): the loop body is
+    // gate backward -> phase B for every wave, and what differs is where the join falls.  Waves 0-3 join after
+    // phase B: their interval is [gate backward of tile k + 1, phase B of tile k].  Waves 4-7 join between the
+    // two, so that phase B of a pass already works on tile k + 1: their interval is [phase B of tile k, gate
+    // backward of tile k + 1].  Every wave passes the same number of barriers.
+    store_phase(cur, cur_live, nxt);
+    __syncthreads();  // (also the weight image)
+    if (!m_first) run_b();
+    for (int k = 0; k < n_iter; ++k) {
+        nxt2 = tile_ref(k + 2);
+        BSTAMP(s1c);
+        gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ 1) * K::DYH_BYTES);
+        BSTAMP(s1d);
+        BSTAMP_ADD(2, s1c, s1d);  // gate backward of the next tile
+        if (m_first) run_b();
+        join();
+        if (!m_first) run_b();
     }
 #ifdef ISG_STAMPS
     BSTAMP(t_end);
@@ -643,6 +692,8 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     ISG_REQUIRE(dh_above_pool >= 1 && (dh_above_pool & (dh_above_pool - 1)) == 0 && H % dh_above_pool == 0 &&
                     W % dh_above_pool == 0, ISG_EINVAL,
                 "isg_convlstm_bwd_fused: pool %d must be a power of two that divides the %dx%d grid", dh_above_pool, H, W);
+    ISG_REQUIRE(!dx || (long long)B * H * W * dx_channel_stride * 2 < (1LL << 32), ISG_EINVAL,
+                "isg_convlstm_bwd_fused: dx is addressed with 32-bit byte offsets");
     int pool_shift = 0;
     while ((1 << pool_shift) < dh_above_pool) ++pool_shift;
     ISG_REQUIRE(!dx || (dx_channels >= 4 && dx_channels % 4 == 0 && dx_channels <= Cs && dx_channel_stride % 4 == 0 &&

@@ -3,7 +3,7 @@
 
 Builds a SEPARATE library (tools/_build/libisg_stamps.so, -DISG_STAMPS; the shipped libisg.so contains no stamps),
 runs the fused backward step at the benchmark shape for both layer shapes and prints the share of each phase for
-waves 0 and 7 (median over workgroups).  The fences around the stamps forbid overlaps the real kernel has: read the
+waves 0 (gate backward first) and 7 (phase B first), median over workgroups.  The fences around the stamps forbid overlaps the real kernel has: read the
 shares, not the total.   usage: stamp_bwd.py --build (on the CPU box), then stamp_bwd.py on the GPU box."""
 import ctypes
 import os
@@ -28,8 +28,8 @@ def main():
     lib.isg_debug_set_bwd_stamp_buffer.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda:0")
     B, P, F, dt = 64, 224, 16, torch.bfloat16
-    names = ["phase A (gate bwd + LDS + load issue)", "barrier after A", "dgrad k-loop", "dgrad stores", "wgrad k-loop",
-             "barrier after B", "total", "tiles"]
+    names = ["store phase ([x | h_prev] tile to LDS)", "barrier after the store phase", "gate backward of the next tile",
+             "dgrad k-loop + stores", "wgrad k-loop", "barrier closing the interval", "total", "tiles"]
     for cs, c_real, hist in ((32, 33, 1), (16, 16, 0)):
         w_x = torch.randn([3, 3, c_real, 64], device=dev) * 0.05
         w_h = torch.randn([3, 3, F, 64], device=dev) * 0.05
