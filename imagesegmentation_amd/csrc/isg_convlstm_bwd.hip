@@ -2,18 +2,20 @@
 //
 // The three-kernel backward (pointwise -> dY in HBM -> data gradient and weight gradient each reading dY back)
 // moves dY three times: 384 of its ~1,000 bytes per pixel.  Here the pre-activation gradient dY exists only in
-// LDS.  Per 8 x 32 (or 4 x 32) pixel tile a 512-thread workgroup
-//   A. computes dY for the tile AND its one-pixel halo from the saved gate activations, cell states and the
-//      incoming gradients (the halo pixels' values are recomputed by the neighbouring tiles, bit for bit the
-//      same), writes it to LDS twice - a padded pixel-major halo image for the data gradient's B operand and an
-//      unpadded interior image in 64-byte regions for the weight gradient's transposing reads - stores dc_prev
-//      for the tile's own pixels, and stages the [x | h_prev] halo tile beside it;
-//   B. runs the data gradient (each wave one tile row x one 32-row tile of input channels, weight image resident
-//      in LDS) and stores dx / dh_prev, then the weight gradient (each wave a group of taps x one 32-column half
-//      of dY; the accumulators stay in registers over all tiles and leave as one slab per workgroup).
-// The next tile's operands are requested pass by pass as phase A frees the registers that held this tile's, so
-// loads are in flight through the whole of phase B: the kernel is HBM-bound (about 650 - 900 bytes per pixel
-// against ~150 MFMA per tile per SIMD).
+// LDS.  Per 8 x 32 (or 4 x 32) pixel tile a 512-thread workgroup runs
+//   - the gate backward: dY for the tile AND its one-pixel halo from the saved gate activations, cell states and
+//     the incoming gradients (the halo pixels' values are recomputed by the neighbouring tiles, bit for bit the
+//     same) into a padded pixel-major halo image in LDS; dc_prev of the tile's own pixels goes to global memory;
+//   - a short store phase that puts the [x | h_prev] halo tile beside it (64-byte regions of 32 channels);
+//   - phase B: the weight gradient (each wave a group of taps x one 32-column half of dY, both operands through
+//     transposing LDS reads; the accumulators stay in registers over all tiles and leave as one slab per
+//     workgroup), then the data gradient (each wave one tile row x one 32-row tile of input channels, weight
+//     image resident in LDS) with its dx / dh_prev stores.
+// Three tiles are in flight: there are TWO dY images, so the gate backward of tile n + 1 (vector ALU) runs while
+// phase B of tile n (matrix pipe) reads the other image, in opposite order on the two waves of every SIMD, and
+// the operands of tile n + 2 are requested into each staging register as the gate backward frees it.
+// What bounds it: the vector ALU (about 1,300 instructions per wave and tile, two thirds of them unpacking,
+// addressing and converting around the gate arithmetic) with ~650 - 900 bytes per pixel in flight behind it.
 #include <utility>
 
 #include "isg_convlstm_shared.h"
