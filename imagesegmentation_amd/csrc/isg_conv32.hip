@@ -1,6 +1,7 @@
-// The encoder's 32 -> 32 channel convolutions (3 x 3 and 5 x 5 taps, SAME padding; reference
-// polyrnn/RNNConvExperiment's second and third tf.layers.conv2d, pattern of
-// polyrnn/History2LargeExperiment.py:15-22) as MFMA kernels, bf16 with float accumulation.
+// The encoder's C -> C channel convolutions, C = 32 or 16 (3 x 3 and 5 x 5 taps, SAME padding; reference
+// polyrnn/RNNConvExperiment's second and third tf.layers.conv2d and the 16-channel layers of
+// polyrnn/History2LargeExperiment.py:15-22) as MFMA kernels, bf16 with float accumulation.  With 16 channels
+// the 32-row MFMA tile is half zero rows: these layers move 64 bytes per pixel, the matrix pipe has room.
 //   forward / data gradient:  D[row][pixel] = sum_k A[row][k] * X[k][pixel]; the caller's weight image
 //       decides which of the two it is (data gradient = flipped taps, transposed channels);
 //       optional bias and ReLU in the epilogue.
@@ -19,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int C = 32;           // channels in and out
+constexpr int MROWS = 32;       // rows of one MFMA tile: the output channels, zero rows above the real ones
 constexpr int TW = 32;
 constexpr int kThreads = 512;   // 8 waves
 
@@ -44,31 +45,34 @@ int num_cus() {
 // ---------------------------------------------------------------------------------------------
 // forward / data gradient
 // ---------------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, int CH>
 struct CF {
+    static_assert(CH == 16 || CH == 32, "channels in = channels out = 16 or 32");
     static constexpr int TH = 16;                     // tile rows: 2 per wave
     static constexpr int PAD = (KS - 1) / 2;
-    static constexpr int NS = KS * KS * 2;            // k-steps: taps x two 16-channel halves
+    static constexpr int SPT = CH / 16;               // k-steps per tap: 16-channel groups
+    static constexpr int NCHK = CH / 8;               // 16-byte chunks per pixel
+    static constexpr int NS = KS * KS * SPT;
     static constexpr int HH = TH + KS - 1, HWP = TW + KS - 1;
     static constexpr int NPIX = HH * HWP;
-    static constexpr int PSTRIDE = C * 2 + 16;        // pad spreads the 16-byte operand reads over the banks
+    static constexpr int PSTRIDE = CH * 2 + 16;       // pad spreads the 16-byte operand reads over the banks
     static constexpr int IN_BYTES = NPIX * PSTRIDE;
     static constexpr int W_BYTES = NS * 1024;
-    static constexpr int NLOAD = (NPIX * 4 + kThreads - 1) / kThreads;
-    static constexpr int LDS_BYTES = W_BYTES + IN_BYTES + C * 4;
+    static constexpr int NLOAD = (NPIX * NCHK + kThreads - 1) / kThreads;
+    static constexpr int LDS_BYTES = W_BYTES + IN_BYTES + MROWS * 4;
 };
 
 struct Conv32Params {
-    const void* x;     // [B,H,W,32] bf16
+    const void* x;     // [B,H,W,CH] bf16
     const void* wimg;  // [NS][64][8] bf16
-    const float* bias; // [32] or null
-    void* y;           // [B,H,W,32] bf16
+    const float* bias; // [CH] or null
+    void* y;           // [B,H,W,CH] bf16
     int B, H, W, tiles_x, tiles_y, relu;
 };
 
-template <int KS>
+template <int KS, int CH>
 __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
-    using K = CF<KS>;
+    using K = CF<KS, CH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
     char* lds_in = smem + K::W_BYTES;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         const uint4* src = static_cast<const uint4*>(p.wimg);
         uint4* dst = reinterpret_cast<uint4*>(lds_w);
         for (int i = tid; i < K::W_BYTES / 16; i += kThreads) dst[i] = src[i];
-        if (tid < C) lds_bias[tid] = p.bias ? p.bias[tid] : 0.0f;
+        if (tid < MROWS) lds_bias[tid] = p.bias && tid < CH ? p.bias[tid] : 0.0f;
     }
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ntiles = tiles_per_img * p.B;
@@ -101,13 +105,13 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
             const int idx = tid + kThreads * j;
-            const int px = idx >> 2, ch = idx & 3;
+            const int px = idx / K::NCHK, ch = idx % K::NCHK;
             const int hy = px / K::HWP, hx = px - hy * K::HWP;
             const int gy = ty0 + hy - K::PAD, gx = tx0 + hx - K::PAD;
             const bool inside = px < K::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             st[j] = make_uint4(0u, 0u, 0u, 0u);
             if (inside) st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.x) +
-                                                                (((size_t)b * p.H + gy) * p.W + gx) * (C * 2) + ch * 16);
+                                                                (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2) + ch * 16);
         }
     };
     auto stage_store = [&](int k) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
             const int idx = tid + kThreads * j;
-            const int px = idx >> 2, ch = idx & 3;
+            const int px = idx / K::NCHK, ch = idx % K::NCHK;
             if (px < K::NPIX) *reinterpret_cast<uint4*>(lds_in + px * K::PSTRIDE + ch * 16) = st[j];
         }
     };
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
             const char* aw = lds_w + lane * 16;
 #pragma unroll 6
             for (int s = 0; s < K::NS; ++s) {
-                const int tap = s >> 1, q = s & 1;
+                const int tap = s / K::SPT, q = s % K::SPT;
                 const int ty = tap / KS, tx = tap - ty * KS;
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
 #pragma unroll
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                     }
                     pk[g][0] = pack2(v[0], v[1]), pk[g][1] = pack2(v[2], v[3]);
                 }
-                unsigned recv[2][2];
+                unsigned recv[K::SPT][2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < K::SPT; ++c)
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
                         const unsigned send = half ? pk[2 * c][w] : pk[2 * c + 1][w];
@@ -172,9 +176,9 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                     }
                 const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
                 if (gy < p.H && gx < p.W) {
-                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (C * 2);
+                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < K::SPT; ++c) {
                         const int g = 2 * c + half;
                         const uint4 out = half ? make_uint4(recv[c][0], recv[c][1], pk[g][0], pk[g][1])
                                                : make_uint4(pk[g][0], pk[g][1], recv[c][0], recv[c][1]);
@@ -194,8 +198,9 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kWgBlocks = 256;
 
-template <int KS>
+template <int KS, int CH>
 struct CWG {
+    static constexpr int NCHK = CH / 8;                 // real 16-byte chunks per pixel (the LDS rows keep 4)
     static constexpr int TH = 8;
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int NT = KS * KS;                  // one 32 x 32 output tile per tap
@@ -213,15 +218,15 @@ struct CWG {
 };
 
 struct Conv32WgradParams {
-    const void* x;   // [B,H,W,32] bf16
-    const void* dz;  // [B,H,W,32] bf16
+    const void* x;   // [B,H,W,CH] bf16
+    const void* dz;  // [B,H,W,CH] bf16
     float* slab;     // [blocks][NT][32][32]
     int B, H, W, tiles_x, tiles_y;
 };
 
-template <int KS>
+template <int KS, int CH>
 __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParams p) {
-    using K = CWG<KS>;
+    using K = CWG<KS, CH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,10 +259,11 @@ __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParam
             const int px = idx >> 2, ch = idx & 3;
             const int hy = px / K::HWP, hx = px - hy * K::HWP;
             const int gy = ty0 + hy - K::PAD, gx = tx0 + hx - K::PAD;
-            const bool inside = px < K::NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            // (16 channels: the LDS rows keep their 64 bytes, the upper half zero - same reads, half-empty tiles)
+            const bool inside = px < K::NPIX && ch < K::NCHK && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             stx[j] = make_uint4(0u, 0u, 0u, 0u);
             if (inside) stx[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.x) +
-                                                                 (((size_t)b * p.H + gy) * p.W + gx) * 64 + ch * 16);
+                                                                 (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2) + ch * 16);
         }
 #pragma unroll
         for (int j = 0; j < K::NLZ; ++j) {
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParam
             const int px = idx >> 2, ch = idx & 3;
             const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
             stz[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (gy < p.H && gx < p.W)
+            if (gy < p.H && gx < p.W && ch < K::NCHK)
                 stz[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.dz) +
-                                                         (((size_t)b * p.H + gy) * p.W + gx) * 64 + ch * 16);
+                                                         (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2) + ch * 16);
         }
     };
     auto stage_store = [&](int k, char* buf) {
@@ -355,52 +361,79 @@ __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParam
     }
 }
 
-// dw[tap][cin][cout] = sum over blocks of slab[block][tap][cin][cout]: the slab layout is HWIO already.
+// dw[tap][cin][cout] = sum over blocks of slab[block][tap][cin][cout] (32 x 32 per tap, of which ch x ch are real).
 // A workgroup owns 64 outputs; 4 groups of 64 threads sum a quarter of the slabs each.
-__global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int n,
-                                                                float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, int ntaps,
+                                                                int ch, float* __restrict__ dw) {
     __shared__ float red[4][64];
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
+    const int idx = blockIdx.x * 64 + o, n = ntaps * ch * ch;
     float s = 0.0f;
-    if (idx < n)
-        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * n + idx];
+    if (idx < n) {
+        const int tap = idx / (ch * ch), r = idx - tap * ch * ch, cin = r / ch, cout = r - cin * ch;
+        const size_t at = ((size_t)tap * 32 + cin) * 32 + cout, per_block = (size_t)ntaps * 32 * 32;
+        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * per_block + at];
+    }
     red[sg][o] = s;
     __syncthreads();
     if (sg == 0 && idx < n) dw[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
-template <int KS>
+template <int KS, int CH>
 int launch_conv32(Conv32Params& p, hipStream_t s) {
-    using K = CF<KS>;
+    using K = CF<KS, CH>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
     p.tiles_x = (p.W + TW - 1) / TW, p.tiles_y = (p.H + K::TH - 1) / K::TH;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int per_cu = (160 * 1024) / K::LDS_BYTES >= 2 ? 2 : 1;
     const int grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<KS, CH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv32_kernel<KS>, dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv32_kernel<KS, CH>), dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
     return isg::check_launch("conv32_kernel");
 }
 
-template <int KS>
+template <int KS, int CH>
 int launch_conv32_wgrad(Conv32WgradParams& p, float* dw, hipStream_t s) {
-    using K = CWG<KS>;
+    using K = CWG<KS, CH>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
     p.tiles_x = (p.W + TW - 1) / TW, p.tiles_y = (p.H + K::TH - 1) / K::TH;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int grid = ntiles < kWgBlocks ? ntiles : kWgBlocks;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_wgrad_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_wgrad_kernel<KS, CH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv32_wgrad_kernel<KS>, dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv32_wgrad_kernel<KS, CH>), dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
     int rc = isg::check_launch("conv32_wgrad_kernel");
     if (rc != ISG_OK) return rc;
-    const int n = K::NT * 32 * 32;
-    hipLaunchKernelGGL(conv32_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, p.slab, grid, n, dw);
+    const int n = K::NT * CH * CH;
+    hipLaunchKernelGGL(conv32_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, p.slab, grid, K::NT, CH, dw);
     return isg::check_launch("conv32_wgrad_reduce_kernel");
+}
+
+int conv_same(const char* who, int CH, const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS,
+              int relu, void* y, void* stream) {
+    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "%s: kernel size %d has no instantiation (3, 5)", who, KS);
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "%s: bad shape", who);
+    ISG_REQUIRE(x && wimg && y, ISG_EINVAL, "%s: null pointer", who);
+    Conv32Params p = {};
+    p.x = x, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (CH == 32) return KS == 3 ? launch_conv32<3, 32>(p, s) : launch_conv32<5, 32>(p, s);
+    return KS == 3 ? launch_conv32<3, 16>(p, s) : launch_conv32<5, 16>(p, s);
+}
+
+int conv_same_wgrad(const char* who, int CH, const void* x, const void* dz, int B, int H, int W, int KS, void* workspace,
+                    float* dw, void* stream) {
+    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "%s: kernel size %d has no instantiation (3, 5)", who, KS);
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "%s: bad shape", who);
+    ISG_REQUIRE(x && dz && workspace && dw, ISG_EINVAL, "%s: null pointer", who);
+    Conv32WgradParams p = {};
+    p.x = x, p.dz = dz, p.slab = static_cast<float*>(workspace), p.B = B, p.H = H, p.W = W;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (CH == 32) return KS == 3 ? launch_conv32_wgrad<3, 32>(p, dw, s) : launch_conv32_wgrad<5, 32>(p, dw, s);
+    return KS == 3 ? launch_conv32_wgrad<3, 16>(p, dw, s) : launch_conv32_wgrad<5, 16>(p, dw, s);
 }
 
 }  // namespace
@@ -412,13 +445,7 @@ extern "C" long long isg_conv32_packed_elems(int KS) {
 
 extern "C" int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
                           void* y, void* stream) {
-    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "isg_conv32: kernel size %d has no instantiation (3, 5)", KS);
-    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv32: bad shape");
-    ISG_REQUIRE(x && wimg && y, ISG_EINVAL, "isg_conv32: null pointer");
-    Conv32Params p = {};
-    p.x = x, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return KS == 3 ? launch_conv32<3>(p, s) : launch_conv32<5>(p, s);
+    return conv_same("isg_conv32", 32, x, wimg, bias, B, H, W, KS, relu, y, stream);
 }
 
 extern "C" long long isg_conv32_wgrad_workspace_bytes(int KS) {
@@ -428,11 +455,23 @@ extern "C" long long isg_conv32_wgrad_workspace_bytes(int KS) {
 
 extern "C" int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                                 void* stream) {
-    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "isg_conv32_wgrad: kernel size %d has no instantiation (3, 5)", KS);
-    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv32_wgrad: bad shape");
-    ISG_REQUIRE(x && dz && workspace && dw, ISG_EINVAL, "isg_conv32_wgrad: null pointer");
-    Conv32WgradParams p = {};
-    p.x = x, p.dz = dz, p.slab = static_cast<float*>(workspace), p.B = B, p.H = H, p.W = W;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return KS == 3 ? launch_conv32_wgrad<3>(p, dw, s) : launch_conv32_wgrad<5>(p, dw, s);
+    return conv_same_wgrad("isg_conv32_wgrad", 32, x, dz, B, H, W, KS, workspace, dw, stream);
+}
+
+// the same four for 16 -> 16 channels (one k-step per tap; dw is [KS][KS][16][16])
+extern "C" long long isg_conv16_packed_elems(int KS) {
+    if (KS != 3 && KS != 5) return -1;
+    return (long long)KS * KS * 64 * 8;
+}
+
+extern "C" int isg_conv16(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
+                          void* y, void* stream) {
+    return conv_same("isg_conv16", 16, x, wimg, bias, B, H, W, KS, relu, y, stream);
+}
+
+extern "C" long long isg_conv16_wgrad_workspace_bytes(int KS) { return isg_conv32_wgrad_workspace_bytes(KS); }
+
+extern "C" int isg_conv16_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
+                                void* stream) {
+    return conv_same_wgrad("isg_conv16_wgrad", 16, x, dz, B, H, W, KS, workspace, dw, stream);
 }

@@ -446,29 +446,33 @@ def conv_in_wgrad(x4, dz, ks):
 
 # ---- the encoder's 32 -> 32 channel convolutions (3 x 3 / 5 x 5 taps, bf16) ---------------------------
 def conv32_supported(w_hwio, dtype, device):
+    """Whether the hand-written C -> C encoder kernels take this layer: square 3 x 3 or 5 x 5, C = 32 or 16, bf16."""
     kh, kw, cin, cout = w_hwio.shape
-    return (kh == kw and cin == 32 and cout == 32 and dtype == torch.bfloat16 and device.type == "cuda" and
+    return (kh == kw and cin == cout and cin in (16, 32) and dtype == torch.bfloat16 and device.type == "cuda" and
             _lib.lib().isg_conv32_packed_elems(int(kh)) > 0)
 
 
 def conv32_pack(w_hwio, data_gradient=False):
-    """HWIO float weights [KS,KS,32,32] -> the kernel's bf16 A-fragment image [KS*KS*2, 64, 8]; with
-    ``data_gradient`` the image of the transposed convolution (flipped taps, channels swapped)."""
+    """HWIO float weights [KS,KS,C,C] (C = 32 or 16) -> the kernel's bf16 A-fragment image [KS*KS*C/16, 64, 8]
+    (output-channel rows padded to the 32 of an MFMA tile); with ``data_gradient`` the image of the transposed
+    convolution (flipped taps, channels swapped)."""
     w = w_hwio.detach().float()
     if data_gradient:
         w = w.flip(0, 1).permute(0, 1, 3, 2)
-    ks = w.shape[0]
-    w = w.reshape(ks * ks, 2, 2, 8, 32).permute(0, 1, 2, 4, 3)  # [tap, q, kg, m, j]
-    return w.reshape(ks * ks * 2, 64, 8).to(torch.bfloat16).contiguous()
+    ks, c = w.shape[0], w.shape[2]
+    w = torch.nn.functional.pad(w, (0, 32 - c))                         # [ks, ks, cin, 32 rows]
+    w = w.reshape(ks * ks, c // 16, 2, 8, 32).permute(0, 1, 2, 4, 3)    # [tap, q, kg, m, j]
+    return w.reshape(ks * ks * (c // 16), 64, 8).to(torch.bfloat16).contiguous()
 
 
 def conv32(x, wimg, bias, ks, relu):
     B, H, W, c = x.shape
-    assert c == 32 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert c in (16, 32) and x.dtype == torch.bfloat16 and x.is_contiguous()
     y = torch.empty_like(x)
-    rc = _lib.lib().isg_conv32(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)),
-                               _lib.ptr(y), _lib.current_stream())
-    _lib.check(rc, "isg_conv32")
+    fn = _lib.lib().isg_conv32 if c == 32 else _lib.lib().isg_conv16
+    rc = fn(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)), _lib.ptr(y),
+            _lib.current_stream())
+    _lib.check(rc, "isg_conv%d" % c)
     return y
 
 
@@ -476,17 +480,17 @@ _conv32_ws = {}
 
 
 def conv32_wgrad(x, dz, ks):
-    B, H, W, _ = x.shape
-    assert x.is_contiguous() and dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == x.shape
+    B, H, W, c = x.shape
+    assert x.is_contiguous() and dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == x.shape and c in (16, 32)
     key = (int(ks), str(x.device))
     ws = _conv32_ws.get(key)
     if ws is None:
         ws = torch.empty([_lib.lib().isg_conv32_wgrad_workspace_bytes(int(ks)) // 4], dtype=torch.float32,
                          device=x.device)
         _conv32_ws[key] = ws
-    dw = torch.empty([ks, ks, 32, 32], dtype=torch.float32, device=x.device)
-    rc = _lib.lib().isg_conv32_wgrad(_lib.ptr(x), _lib.ptr(dz), B, H, W, int(ks), _lib.ptr(ws), _lib.ptr(dw),
-                                     _lib.current_stream())
+    dw = torch.empty([ks, ks, c, c], dtype=torch.float32, device=x.device)
+    fn = _lib.lib().isg_conv32_wgrad if c == 32 else _lib.lib().isg_conv16_wgrad
+    rc = fn(_lib.ptr(x), _lib.ptr(dz), B, H, W, int(ks), _lib.ptr(ws), _lib.ptr(dw), _lib.current_stream())
     _lib.check(rc, "isg_conv32_wgrad")
     return dw
 

@@ -370,6 +370,18 @@ long long isg_conv32_wgrad_workspace_bytes(int KS);
 int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                      void* stream);
 
+/* ---- the same for 16 -> 16 channels ---------------------------------------------------------------------
+ * The 16-channel encoder layers of reference polyrnn/History2LargeExperiment.py:15-22 (5 x 5 and 3 x 3) and of
+ * polyrnn/EndTokenDeepExperiment_2.py.  Same kernels with one 16-channel k-step per tap:
+ * wimg bf16 [KS*KS][64][8], element [tap][32 kg + m][j] = A[tap][m][8 kg + j] with rows m >= 16 zero;
+ * x, y, dz [B][H][W][16]; dw float [KS][KS][16][16]. */
+long long isg_conv16_packed_elems(int KS);
+int isg_conv16(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
+               void* stream);
+long long isg_conv16_wgrad_workspace_bytes(int KS);
+int isg_conv16_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

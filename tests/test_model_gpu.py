@@ -289,30 +289,34 @@ def test_first_encoder_convolution_kernels_against_float64_conv():
     assert rel_err(dw, ref_dw) < 1e-4  # float accumulation of exact bf16 products
 
 
+@pytest.mark.parametrize("C", [32, 16])
 @pytest.mark.parametrize("KS", [3, 5])
-def test_encoder_32_channel_convolution_kernels_against_float64_conv(KS):
-    """isg_conv32 (forward with bias + ReLU, data gradient) and isg_conv32_wgrad against the oracle's float64
-    convolution on bf16-rounded operands; ragged image size so that partial tiles are covered."""
+def test_encoder_square_convolution_kernels_against_float64_conv(KS, C):
+    """isg_conv32 / isg_conv16 (forward with bias + ReLU, data gradient) and their weight gradients against the
+    oracle's float64 convolution on bf16-rounded operands; ragged image size so that partial tiles are covered."""
     from imagesegmentation_amd import ops
-    rs = np.random.RandomState(KS)
+    rs = np.random.RandomState(KS + C)
     B, H, W = 2, 37, 45
     r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
-    x = r(rs.randn(B, H, W, 32))
-    w = r(rs.randn(KS, KS, 32, 32) * 0.05)
-    bias = rs.randn(32) * 0.1
+    x = r(rs.randn(B, H, W, C))
+    w = r(rs.randn(KS, KS, C, C) * 0.05)
+    bias = rs.randn(C) * 0.1
     dev = "cuda:0"
     bf = lambda a: torch.tensor(a, device=dev).to(torch.bfloat16)
     tw = torch.tensor(w, dtype=torch.float32, device=dev)
     tb = torch.tensor(bias, dtype=torch.float32, device=dev)
+    assert ops.conv32_supported(tw, torch.bfloat16, tw.device)
     y = ops.conv32(bf(x), ops.conv32_pack(tw), tb, KS, relu=True)
+    assert y.shape == (B, H, W, C)
     assert rel_err(y, np.maximum(oc.conv2d_same(x, w, bias), 0.0)) < 1e-2  # bf16 output rounding
     y_lin = ops.conv32(bf(x), ops.conv32_pack(tw), None, KS, relu=False)
     assert rel_err(y_lin, oc.conv2d_same(x, w)) < 1e-2
-    dz = r(rs.randn(B, H, W, 32))
+    dz = r(rs.randn(B, H, W, C))
     ref_dx, ref_dw, _ = oc.conv2d_same_backward(x, w, dz)
     dx = ops.conv32(bf(dz), ops.conv32_pack(tw, data_gradient=True), None, KS, relu=False)
     assert rel_err(dx, ref_dx) < 1e-2
     dw = ops.conv32_wgrad(bf(x), bf(dz), KS)
+    assert dw.shape == (KS, KS, C, C)
     assert rel_err(dw, ref_dw) < 1e-4  # float accumulation of exact bf16 products
 
 
