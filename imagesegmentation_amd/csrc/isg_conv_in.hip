@@ -1,6 +1,7 @@
-// The encoder's first convolution: KS x KS taps over an image with at most 4 channels -> 32 channels,
-// TensorFlow SAME padding, + bias + ReLU in the epilogue (reference polyrnn/RNNConvExperiment's 14 x 14
-// layer; tf.layers.conv2d(..., activation=tf.nn.relu), polyrnn/History2LargeExperiment.py:15-22).
+// The encoder's first convolution: KS x KS taps over an image with at most 4 channels -> CO = 32 or 16
+// channels, TensorFlow SAME padding, + bias + ReLU in the epilogue (reference polyrnn/RNNConvExperiment's
+// 14 x 14 -> 32 layer and the 5 x 5 -> 16 layer of polyrnn/History2LargeExperiment.py:15-22;
+// tf.layers.conv2d(..., activation=tf.nn.relu)).  With 16 output channels half the MFMA rows are zero.
 // A library implicit GEMM spends most of its K on padding when the image has 3 channels; here the
 // reduction index is (ky, kx, c) with c padded to 4 only, so one 16-deep MFMA step covers 4
 // horizontal taps, and the B operand of a lane is 16 contiguous bytes of the staged image tile.
@@ -15,7 +16,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TH = 8, TW = 32, COUT = 32, kThreads = 256;
+constexpr int TH = 8, TW = 32, MROWS = 32, kThreads = 256;
 
 template <int KS>
 struct CI {
@@ -29,14 +30,14 @@ struct CI {
     static constexpr int IN_BYTES = NPIX * 8;         // 4 channels x bf16 per pixel
     static constexpr int W_BYTES = NS * 1024;
     static constexpr int NLOAD = (NPIX + kThreads - 1) / kThreads;
-    static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + COUT * 4;
+    static constexpr int LDS_BYTES = W_BYTES + 2 * IN_BYTES + MROWS * 4;
 };
 
 struct ConvInParams {
     const void* x4;    // [B,H,W,4] bf16, channel 3 = 0
     const void* wimg;  // [NS][64 lanes][8] bf16 A fragments
-    const float* bias; // [32]
-    void* y;           // [B,H,W,32] bf16
+    const float* bias; // [CO]
+    void* y;           // [B,H,W,CO] bf16
     int B, H, W, tiles_x, tiles_y, relu;
 };
 
@@ -46,8 +47,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KS>
+template <int KS, int CO>
 __global__ __launch_bounds__(kThreads) void conv_in_fwd_kernel(ConvInParams p) {
+    static_assert(CO == 16 || CO == 32, "output channels");
     using K = CI<KS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(kThreads) void conv_in_fwd_kernel(ConvInParams p) {
         const uint4* src = static_cast<const uint4*>(p.wimg);
         uint4* dst = reinterpret_cast<uint4*>(lds_w);
         for (int i = tid; i < K::W_BYTES / 16; i += kThreads) dst[i] = src[i];
-        if (tid < COUT) lds_bias[tid] = p.bias[tid];
+        if (tid < MROWS) lds_bias[tid] = tid < CO ? p.bias[tid] : 0.0f;
     }
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ntiles = tiles_per_img * p.B;
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(kThreads) void conv_in_fwd_kernel(ConvInParams p) {
                     pk[g][0] = pack2(v[0], v[1]), pk[g][1] = pack2(v[2], v[3]);
                 }
                 // half 0 keeps groups 0 and 2 (stores chunks 0 and 2), half 1 keeps 1 and 3 (chunks 1 and 3)
-                unsigned recv[2][2];
+                unsigned recv[CO / 16][2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < CO / 16; ++c)
 #pragma unroll
                     for (int w = 0; w < 2; ++w) {
                         const unsigned send = half ? pk[2 * c][w] : pk[2 * c + 1][w];
@@ -154,9 +156,9 @@ __global__ __launch_bounds__(kThreads) void conv_in_fwd_kernel(ConvInParams p) {
                     }
                 const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
                 if (gy < p.H && gx < p.W) {
-                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (COUT * 2);
+                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (CO * 2);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < CO / 16; ++c) {
                         const int g = 2 * c + half;  // own group = chunk index
                         const uint4 out = half ? make_uint4(recv[c][0], recv[c][1], pk[g][0], pk[g][1])
                                                : make_uint4(pk[g][0], pk[g][1], recv[c][0], recv[c][1]);
@@ -197,26 +199,27 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <int KS>
 struct CW {
     using F = CI<KS>;
-    static constexpr int NT = 2 * KS;                    // output tiles (ky, row tile)
+    static constexpr int MTW = F::KXP * 4 / 32;          // 32-row tiles per kernel row: (kx, c) pairs / 32
+    static constexpr int NT = MTW * KS;                  // output tiles (ky, row tile)
     static constexpr int TPW = (NT + 3) / 4;             // tiles per wave group
     static constexpr int DZ_BYTES = TH * TW * 64;
     static constexpr int BUF_BYTES = F::IN_BYTES + DZ_BYTES;
     static constexpr int NLX = (F::NPIX + kWgThreads - 1) / kWgThreads;
     static constexpr int NLZ = (TH * TW * 4) / kWgThreads;
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-    static_assert(F::KXP == 16, "two 32-row tiles of 8 taps x 4 channels");
+    static_assert(F::KXP % 8 == 0, "whole 32-row tiles of 8 taps x 4 channels");
     static_assert((TH * TW * 4) % kWgThreads == 0, "dZ tile must fill whole passes");
     static_assert(4 * 16 * 64 * 4 <= LDS_BYTES, "reduction scratch");
 };
 
 struct ConvInWgradParams {
     const void* x4;  // [B,H,W,4] bf16
-    const void* dz;  // [B,H,W,32] bf16
+    const void* dz;  // [B,H,W,CO] bf16
     float* slab;     // [blocks][NT][32][32]
     int B, H, W, tiles_x, tiles_y;
 };
 
-template <int KS>
+template <int KS, int CO>
 __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradParams p) {
     using K = CW<KS>;
     using F = CI<KS>;
@@ -263,9 +266,9 @@ __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradPa
             const int px = idx >> 2, ch = idx & 3;
             const int gy = ty0 + px / TW, gx = tx0 + (px & (TW - 1));
             stz[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (gy < p.H && gx < p.W)
+            if (gy < p.H && gx < p.W && ch < CO / 8)  // (16 channels: the upper half of the 64-byte LDS row stays zero)
                 stz[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.dz) +
-                                                         (((size_t)b * p.H + gy) * p.W + gx) * 64 + ch * 16);
+                                                         (((size_t)b * p.H + gy) * p.W + gx) * (CO * 2) + ch * 16);
         }
     };
     auto stage_store = [&](int k, char* buf) {
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradPa
             for (int i = 0; i < K::TPW; ++i) {
                 if (i < nt) {
                     const int t = t0 + i;
-                    const int ky = t >> 1, mt = t & 1;
+                    const int ky = t / K::MTW, mt = t % K::MTW;
                     const char* a0 = lds_in + ((r + ky) * F::ROWPX + pj) * 8 + (32 * mt + csub) * 2;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -354,20 +357,22 @@ __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradPa
     }
 }
 
-// dw[ky][kx][c][o] = sum over blocks of slab[block][2 ky + kx / 8][(kx % 8) * 4 + c][o].
+// dw[ky][kx][c][o] = sum over blocks of slab[block][MTW ky + (4 kx + c) / 32][(4 kx + c) % 32][o].
 // A workgroup owns 64 outputs; 4 groups of 64 threads sum a quarter of the slabs each.
-template <int KS>
+template <int KS, int CO>
 __global__ __launch_bounds__(256) void conv_in_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks,
                                                                  float* __restrict__ dw) {
+    using K = CW<KS>;
     __shared__ float red[4][64];
     const int t = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + t;
-    const bool has = idx < KS * KS * 3 * COUT;
+    const bool has = idx < KS * KS * 3 * CO;
     float s = 0.0f;
     if (has) {
-        const int o = idx % COUT, c = (idx / COUT) % 3, kx = (idx / (COUT * 3)) % KS, ky = idx / (COUT * 3 * KS);
-        const size_t off = ((size_t)(2 * ky + (kx >> 3)) * 32 + (kx & 7) * 4 + c) * 32 + o;
-        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * (2 * KS) * 1024 + off];
+        const int o = idx % CO, c = (idx / CO) % 3, kx = (idx / (CO * 3)) % KS, ky = idx / (CO * 3 * KS);
+        const int v = 4 * kx + c;
+        const size_t off = ((size_t)(K::MTW * ky + v / 32) * 32 + v % 32) * 32 + o;
+        for (int b = sg; b < nblocks; b += 4) s += slab[(size_t)b * K::NT * 1024 + off];
     }
     red[sg][t] = s;
     __syncthreads();
@@ -388,9 +393,43 @@ int num_cus() {
 
 }  // namespace
 
-extern "C" long long isg_conv_in_packed_elems(int KS) {
-    if (KS != 14) return -1;
-    return (long long)CI<14>::NS * 64 * 8;
+namespace {
+bool conv_in_has(int KS, int CO) { return (KS == 14 || KS == 5) && (CO == 32 || CO == 16); }
+
+template <int KS, int CO>
+int launch_conv_in_fwd(ConvInParams& p, hipStream_t s) {
+    using K = CI<KS>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_fwd_kernel<KS, CO>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((conv_in_fwd_kernel<KS, CO>), dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    return isg::check_launch("conv_in_fwd_kernel");
+}
+
+template <int KS, int CO>
+int launch_conv_in_wgrad(ConvInWgradParams& p, float* dw, hipStream_t s) {
+    using K = CW<KS>;
+    static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
+    const int ntiles = p.tiles_x * p.tiles_y * p.B;
+    const int grid = ntiles < kWgBlocks ? ntiles : kWgBlocks;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_wgrad_kernel<KS, CO>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((conv_in_wgrad_kernel<KS, CO>), dim3(grid), dim3(kWgThreads), K::LDS_BYTES, s, p);
+    int rc = isg::check_launch("conv_in_wgrad_kernel");
+    if (rc != ISG_OK) return rc;
+    const int n_out = KS * KS * 3 * CO;
+    hipLaunchKernelGGL((conv_in_wgrad_reduce_kernel<KS, CO>), dim3((n_out + 63) / 64), dim3(256), 0, s, p.slab, grid, dw);
+    return isg::check_launch("conv_in_wgrad_reduce_kernel");
+}
+}  // namespace
+
+extern "C" long long isg_conv_in_packed_elems(int KS, int cout) {
+    if (!conv_in_has(KS, cout)) return -1;
+    return (long long)(KS == 14 ? CI<14>::NS : CI<5>::NS) * 64 * 8;
 }
 
 extern "C" int isg_conv_in_pad_image(const void* x3, long long npix, void* x4, void* stream) {
@@ -403,49 +442,35 @@ extern "C" int isg_conv_in_pad_image(const void* x3, long long npix, void* x4, v
     return isg::check_launch("pad_channels_3to4_kernel");
 }
 
-extern "C" int isg_conv_in_fwd(const void* x4, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
-                               void* y, void* stream) {
-    ISG_REQUIRE(KS == 14, ISG_EINVAL, "isg_conv_in_fwd: kernel size %d has no instantiation (14)", KS);
+extern "C" int isg_conv_in_fwd(const void* x4, const void* wimg, const float* bias, int B, int H, int W, int KS, int cout,
+                               int relu, void* y, void* stream) {
+    ISG_REQUIRE(conv_in_has(KS, cout), ISG_EINVAL, "isg_conv_in_fwd: no instantiation for %d x %d taps -> %d channels "
+                "(14 or 5 taps, 32 or 16 channels)", KS, KS, cout);
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv_in_fwd: bad shape");
     ISG_REQUIRE(x4 && wimg && bias && y, ISG_EINVAL, "isg_conv_in_fwd: null pointer");
-    using K = CI<14>;
     ConvInParams p = {};
     p.x4 = x4, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
-    const int ntiles = p.tiles_x * p.tiles_y * B;
-    const int grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_fwd_kernel<14>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv_in_fwd_kernel<14>, dim3(grid), dim3(kThreads), K::LDS_BYTES, static_cast<hipStream_t>(stream),
-                       p);
-    return isg::check_launch("conv_in_fwd_kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (KS == 14) return cout == 32 ? launch_conv_in_fwd<14, 32>(p, s) : launch_conv_in_fwd<14, 16>(p, s);
+    return cout == 32 ? launch_conv_in_fwd<5, 32>(p, s) : launch_conv_in_fwd<5, 16>(p, s);
 }
 
-extern "C" long long isg_conv_in_wgrad_workspace_bytes(int KS) {
-    if (KS != 14) return -1;
-    return (long long)kWgBlocks * CW<14>::NT * 32 * 32 * (long long)sizeof(float);
+extern "C" long long isg_conv_in_wgrad_workspace_bytes(int KS, int cout) {
+    if (!conv_in_has(KS, cout)) return -1;
+    return (long long)kWgBlocks * (KS == 14 ? CW<14>::NT : CW<5>::NT) * 32 * 32 * (long long)sizeof(float);
 }
 
-extern "C" int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
-                                 void* stream) {
-    ISG_REQUIRE(KS == 14, ISG_EINVAL, "isg_conv_in_wgrad: kernel size %d has no instantiation (14)", KS);
+extern "C" int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int KS, int cout, void* workspace,
+                                 float* dw, void* stream) {
+    ISG_REQUIRE(conv_in_has(KS, cout), ISG_EINVAL, "isg_conv_in_wgrad: no instantiation for %d x %d taps -> %d channels "
+                "(14 or 5 taps, 32 or 16 channels)", KS, KS, cout);
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_conv_in_wgrad: bad shape");
     ISG_REQUIRE(x4 && dz && workspace && dw, ISG_EINVAL, "isg_conv_in_wgrad: null pointer");
-    using K = CW<14>;
     ConvInWgradParams p = {};
     p.x4 = x4, p.dz = dz, p.slab = static_cast<float*>(workspace), p.B = B, p.H = H, p.W = W;
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
-    const int ntiles = p.tiles_x * p.tiles_y * B;
-    const int grid = ntiles < kWgBlocks ? ntiles : kWgBlocks;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_in_wgrad_kernel<14>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv_in_wgrad_kernel<14>, dim3(grid), dim3(kWgThreads), K::LDS_BYTES, s, p);
-    int rc = isg::check_launch("conv_in_wgrad_kernel");
-    if (rc != ISG_OK) return rc;
-    const int n_out = 14 * 14 * 3 * COUT;
-    hipLaunchKernelGGL(conv_in_wgrad_reduce_kernel<14>, dim3((n_out + 63) / 64), dim3(256), 0, s, p.slab, grid, dw);
-    return isg::check_launch("conv_in_wgrad_reduce_kernel");
+    if (KS == 14) return cout == 32 ? launch_conv_in_wgrad<14, 32>(p, dw, s) : launch_conv_in_wgrad<14, 16>(p, dw, s);
+    return cout == 32 ? launch_conv_in_wgrad<5, 32>(p, dw, s) : launch_conv_in_wgrad<5, 16>(p, dw, s);
 }

@@ -392,17 +392,20 @@ def relu_bwd_bias(dy, y):
 
 # ---- the encoder's first convolution (14 x 14 taps, 3 -> 32 channels, bf16) ----------------------
 def conv_in_supported(w_hwio, dtype, device):
+    """Whether the hand-written first-layer kernels take this layer: 3 input channels, square 14 x 14 or 5 x 5
+    taps, 32 or 16 output channels, bf16."""
     kh, kw, cin, cout = w_hwio.shape
-    return (kh == kw and cin == 3 and cout == 32 and dtype == torch.bfloat16 and device.type == "cuda" and
-            _lib.lib().isg_conv_in_packed_elems(int(kh)) > 0)
+    return (kh == kw and cin == 3 and dtype == torch.bfloat16 and device.type == "cuda" and
+            _lib.lib().isg_conv_in_packed_elems(int(kh), int(cout)) > 0)
 
 
 def conv_in_pack(w_hwio):
-    """HWIO float weights [KS,KS,3,32] -> the kernel's bf16 A-fragment image [KS * KXP/4, 64, 8]."""
-    ks = w_hwio.shape[0]
+    """HWIO float weights [KS,KS,3,cout] -> the kernel's bf16 A-fragment image [KS * KXP/4, 64, 8] (output-channel
+    rows padded to the 32 of an MFMA tile)."""
+    ks, cout = w_hwio.shape[0], w_hwio.shape[3]
     kxp = (ks + 3) // 4 * 4
-    w = torch.nn.functional.pad(w_hwio.detach().float(), (0, 0, 0, 1, 0, kxp - ks))  # [KS, KXP, 4, 32]
-    w = w.reshape(ks, kxp // 4, 2, 2, 4, 32).permute(0, 1, 2, 5, 3, 4)               # [ky, s, kg, m, jx, c]
+    w = torch.nn.functional.pad(w_hwio.detach().float(), (0, 32 - cout, 0, 1, 0, kxp - ks))  # [KS, KXP, 4, 32]
+    w = w.reshape(ks, kxp // 4, 2, 2, 4, 32).permute(0, 1, 2, 5, 3, 4)                        # [ky, s, kg, m, jx, c]
     return w.reshape(ks * (kxp // 4), 64, 8).to(torch.bfloat16).contiguous()
 
 
@@ -417,9 +420,10 @@ def conv_in_pad_image(x3):
 
 def conv_in_fwd(x4, wimg, bias, ks, relu=True):
     B, H, W, _ = x4.shape
-    y = torch.empty([B, H, W, 32], dtype=torch.bfloat16, device=x4.device)
-    rc = _lib.lib().isg_conv_in_fwd(_lib.ptr(x4), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)),
-                                    _lib.ptr(y), _lib.current_stream())
+    cout = bias.shape[0]
+    y = torch.empty([B, H, W, cout], dtype=torch.bfloat16, device=x4.device)
+    rc = _lib.lib().isg_conv_in_fwd(_lib.ptr(x4), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(cout),
+                                    int(bool(relu)), _lib.ptr(y), _lib.current_stream())
     _lib.check(rc, "isg_conv_in_fwd")
     return y
 
@@ -428,17 +432,18 @@ _conv_in_ws = {}
 
 
 def conv_in_wgrad(x4, dz, ks):
-    """float32 [KS,KS,3,32] weight gradient from the padded image and the masked output gradient."""
+    """float32 [KS,KS,3,cout] weight gradient from the padded image and the masked output gradient."""
     B, H, W, _ = x4.shape
-    assert dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == (B, H, W, 32)
-    key = (int(ks), str(x4.device))
+    cout = dz.shape[-1]
+    assert dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == (B, H, W, cout)
+    key = (int(ks), int(cout), str(x4.device))
     ws = _conv_in_ws.get(key)
     if ws is None:
-        ws = torch.empty([_lib.lib().isg_conv_in_wgrad_workspace_bytes(int(ks)) // 4], dtype=torch.float32,
+        ws = torch.empty([_lib.lib().isg_conv_in_wgrad_workspace_bytes(int(ks), int(cout)) // 4], dtype=torch.float32,
                          device=x4.device)
         _conv_in_ws[key] = ws
-    dw = torch.empty([ks, ks, 3, 32], dtype=torch.float32, device=x4.device)
-    rc = _lib.lib().isg_conv_in_wgrad(_lib.ptr(x4), _lib.ptr(dz), B, H, W, int(ks), _lib.ptr(ws), _lib.ptr(dw),
+    dw = torch.empty([ks, ks, 3, cout], dtype=torch.float32, device=x4.device)
+    rc = _lib.lib().isg_conv_in_wgrad(_lib.ptr(x4), _lib.ptr(dz), B, H, W, int(ks), int(cout), _lib.ptr(ws), _lib.ptr(dw),
                                       _lib.current_stream())
     _lib.check(rc, "isg_conv_in_wgrad")
     return dw

@@ -64,7 +64,7 @@ class _BiasRelu(torch.autograd.Function):
 
 
 class _ConvIn(torch.autograd.Function):
-    """First encoder layer (image -> 32 channels, SAME, bias, ReLU) on the isg_conv_in kernels.  The
+    """First encoder layer (image -> 32 or 16 channels, SAME, bias, ReLU) on the isg_conv_in kernels.  The
     image gets no gradient (it is the network's input)."""
 
     @staticmethod
@@ -85,7 +85,7 @@ class _ConvIn(torch.autograd.Function):
 
 
 class _Conv32(torch.autograd.Function):
-    """A 32 -> 32 channel encoder layer (SAME, bias, ReLU) on the isg_conv32 kernels: forward with the
+    """A 32 -> 32 or 16 -> 16 channel encoder layer (SAME, bias, ReLU) on the isg_conv32 / isg_conv16 kernels: forward with the
     bias and ReLU fused, backward = ReLU mask + bias gradient, data gradient, weight gradient."""
 
     @staticmethod

@@ -335,23 +335,24 @@ int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, 
                              void* stream);
 
 /* ---- the encoder's first convolution -------------------------------------------------------------
- * KS x KS taps over a 3-channel image -> 32 channels, TensorFlow SAME padding ((KS-1)/2 before, the rest
- * after), + bias (+ ReLU): the first tf.layers.conv2d of reference polyrnn/RNNConvExperiment.py (14 x 14)
- * as one MFMA kernel whose reduction index is (ky, kx, channel padded to 4).  bf16, KS = 14.
+ * KS x KS taps over a 3-channel image -> cout channels, TensorFlow SAME padding ((KS-1)/2 before, the rest
+ * after), + bias (+ ReLU): the first tf.layers.conv2d of reference polyrnn/RNNConvExperiment.py (14 x 14 -> 32)
+ * and of polyrnn/History2LargeExperiment.py:15-17 (5 x 5 -> 16) as one MFMA kernel whose reduction index is
+ * (ky, kx, channel padded to 4).  bf16; KS = 14 or 5, cout = 32 or 16.
  *   isg_conv_in_pad_image:   x3 bf16 [npix][3] -> x4 bf16 [npix][4] (fourth channel 0).
  *   wimg: bf16 [KS * KXP/4][64][8] with KXP = KS rounded up to 4; element [ky * KXP/4 + s][32 kg + m][j] =
- *         w[ky][4 s + 2 kg + j / 4][j % 4][m] (HWIO), 0 where kx >= KS or the channel is 3;
- *         isg_conv_in_packed_elems(KS) gives its length (-1: no such instantiation).
- *   isg_conv_in_fwd:   y bf16 [B][H][W][32] = act(conv(x4, w) + bias), act = ReLU when relu != 0.
- *   isg_conv_in_wgrad: dw float [KS][KS][3][32] (overwritten) = gradient of the convolution for
- *         dz bf16 [B][H][W][32] (the gradient after the ReLU mask, see isg_relu_bwd_bias); workspace:
- *         device scratch of isg_conv_in_wgrad_workspace_bytes(KS) bytes. */
-long long isg_conv_in_packed_elems(int KS);
+ *         w[ky][4 s + 2 kg + j / 4][j % 4][m] (HWIO), 0 where kx >= KS, the channel is 3 or m >= cout;
+ *         isg_conv_in_packed_elems(KS, cout) gives its length (-1: no such instantiation).
+ *   isg_conv_in_fwd:   y bf16 [B][H][W][cout] = act(conv(x4, w) + bias), act = ReLU when relu != 0.
+ *   isg_conv_in_wgrad: dw float [KS][KS][3][cout] (overwritten) = gradient of the convolution for
+ *         dz bf16 [B][H][W][cout] (the gradient after the ReLU mask, see isg_relu_bwd_bias); workspace:
+ *         device scratch of isg_conv_in_wgrad_workspace_bytes(KS, cout) bytes. */
+long long isg_conv_in_packed_elems(int KS, int cout);
 int isg_conv_in_pad_image(const void* x3, long long npix, void* x4, void* stream);
-int isg_conv_in_fwd(const void* x4, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
-                    void* stream);
-long long isg_conv_in_wgrad_workspace_bytes(int KS);
-int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
+int isg_conv_in_fwd(const void* x4, const void* wimg, const float* bias, int B, int H, int W, int KS, int cout, int relu,
+                    void* y, void* stream);
+long long isg_conv_in_wgrad_workspace_bytes(int KS, int cout);
+int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int KS, int cout, void* workspace, float* dw,
                       void* stream);
 
 /* ---- the encoder's 32 -> 32 channel convolutions ----------------------------------------------------

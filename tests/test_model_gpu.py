@@ -265,26 +265,31 @@ def test_fused_bias_relu_and_its_backward(dtype, C):
     assert float((dbias.double() - ref_db).abs().max()) <= 1e-5 * max(1.0, float(ref_db.abs().max()))
 
 
-def test_first_encoder_convolution_kernels_against_float64_conv():
-    """isg_conv_in_fwd / _wgrad (14 x 14 taps, 3 -> 32 channels, SAME, bias, ReLU; bf16) against the oracle's
-    float64 convolution on bf16-rounded operands; ragged image size so that partial tiles are covered."""
+@pytest.mark.parametrize("KS,CO", [(14, 32), (5, 16), (5, 32), (14, 16)])
+def test_first_encoder_convolution_kernels_against_float64_conv(KS, CO):
+    """isg_conv_in_fwd / _wgrad (14 x 14 -> 32 of the benchmark net, 5 x 5 -> 16 of the reference's 28 x 28 nets;
+    3 input channels, SAME, bias, ReLU; bf16) against the oracle's float64 convolution on bf16-rounded operands;
+    ragged image size so that partial tiles are covered."""
     from imagesegmentation_amd import ops
-    rs = np.random.RandomState(14)
-    B, H, W, KS = 2, 37, 45, 14
+    rs = np.random.RandomState(KS + CO)
+    B, H, W = 2, 37, 45
     r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
     x = r(rs.rand(B, H, W, 3))
-    w = r(rs.randn(KS, KS, 3, 32) * 0.05)
-    bias = rs.randn(32) * 0.1
+    w = r(rs.randn(KS, KS, 3, CO) * 0.05)
+    bias = rs.randn(CO) * 0.1
     dev = "cuda:0"
     tw = torch.tensor(w, dtype=torch.float32, device=dev)
     tb = torch.tensor(bias, dtype=torch.float32, device=dev)
+    assert ops.conv_in_supported(tw, torch.bfloat16, tw.device)
     x4 = ops.conv_in_pad_image(torch.tensor(x, device=dev).to(torch.bfloat16))
     assert x4.shape == (B, H, W, 4) and float(x4[..., 3].abs().max()) == 0.0
     y = ops.conv_in_fwd(x4, ops.conv_in_pack(tw), tb, KS, relu=True)
+    assert y.shape == (B, H, W, CO)
     ref = np.maximum(oc.conv2d_same(x, w, bias), 0.0)
     assert rel_err(y, ref) < 1e-2  # bf16 output rounding
-    dz = r(rs.randn(B, H, W, 32))
+    dz = r(rs.randn(B, H, W, CO))
     dw = ops.conv_in_wgrad(x4, torch.tensor(dz, device=dev).to(torch.bfloat16), KS)
+    assert dw.shape == (KS, KS, 3, CO)
     _, ref_dw, _ = oc.conv2d_same_backward(x, w, dz)
     assert rel_err(dw, ref_dw) < 1e-4  # float accumulation of exact bf16 products
 
