@@ -52,8 +52,8 @@ def parse():
                     help="keep MIOpen's immediate-mode pick for the encoder convs instead of letting it time its solvers "
                          "during warm-up")
     ap.add_argument("--a3c-envs", type=int, default=1024, help="actor-critic environments per GPU (0 = skip)")
-    ap.add_argument("--settle-seconds", type=float, default=8.0,
-                    help="idle pause before the warm-up (see main: the after-effect of a process that just ended)")
+    ap.add_argument("--settle-seconds", type=float, default=0.0,
+                    help="idle pause before the warm-up (diagnostic; see main)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: every rank joins the process group (ISG_DIST_BACKEND, default nccl), runs the "
                          "timed region's fences and reductions around an empty step on host tensors, and rank 0 prints "
@@ -477,16 +477,15 @@ def main():
     def step():
         return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
 
-    # A process that starts within a few seconds of the end of another GPU-heavy one on the same device (the
-    # scaling sweep runs N = 1, 2, 4, 8 back to back) was measured launching kernels 10x slower from about half a
-    # second into its steps until about 8 s after the other one ended - host-side issue time 200 ms per step
-    # instead of 2, kernel durations unchanged (tools/exp_steps.py).  Idling through that window keeps it out
-    # of the timed region; it costs nothing the metric counts.
+    # (An earlier build launched kernels 10x slower for the first ~8 s of a process started right behind another
+    # GPU-heavy one, and idled here by default.  It went away with the vendor convolutions - the encoder's solver
+    # search ran inside the first steps of every process: two full default runs back to back now time 10.73 and
+    # 10.67 ms per step without any pause.  The switch stays for diagnosis.)
     if args.settle_seconds > 0:
         note("settling pause of %.0f s" % args.settle_seconds)
         torch.cuda.synchronize()
         time.sleep(args.settle_seconds)
-    note("model and batch ready; warm-up (the first step includes the convolution solver search)")
+    note("model and batch ready; warm-up")
     for _ in range(args.warmup):
         step()
     note("timing %d training steps" % args.steps)

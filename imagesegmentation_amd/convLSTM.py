@@ -559,14 +559,22 @@ class _WideSequenceFunction(torch.autograd.Function):
         k = F // Fh
         groups = _wide_groups(cell, C)
         cs = groups[0][1].cs
-        xw = torch.zeros([max(t_run, 1), B, H, W, cs], dtype=dt, device=dev)
+        keep = not getattr(ctx, "forward_only", False)  # without a backward pass no gates are stored
+        xw = torch.empty([max(t_run, 1), B, H, W, cs], dtype=dt, device=dev)
+        if cs > C + F - Fh or t_run == 0:
+            xw[..., C + F - Fh:] = 0  # padding channels (they meet zero weights, but must be finite)
         xw[:t_run, ..., :C] = x_seq[:t_run].to(dt)
         Hs = [[h0[..., Fh * s:Fh * s + Fh].to(dt).contiguous()] +
               list(torch.empty([t_run, B, H, W, Fh], dtype=dt, device=dev).unbind(0)) for s in range(k)]
         Cs = [[c0[..., Fh * s:Fh * s + Fh].to(torch.float32).contiguous()] +
               list(torch.empty([t_run, B, H, W, Fh], dtype=torch.float32, device=dev).unbind(0)) for s in range(k)]
-        Gs = [torch.empty([t_run, B, H, W, Fh, 4], dtype=dt, device=dev) for _ in range(k)]
-        outs = [torch.zeros([B, T, H, W, Fh], dtype=dt, device=dev) for _ in range(k)]
+        Gs = [torch.empty([t_run, B, H, W, Fh, 4], dtype=dt, device=dev) if keep else None for _ in range(k)]
+        # every step that runs writes its whole output slice (zeros for finished samples): only steps past the
+        # longest sequence need the fill
+        outs = [torch.empty([B, T, H, W, Fh], dtype=dt, device=dev) for _ in range(k)]
+        if t_run < T:
+            for o in outs:
+                o[:, t_run:] = 0
         live = None
         for t in range(t_run):
             for s in range(1, k):
@@ -576,7 +584,7 @@ class _WideSequenceFunction(torch.autograd.Function):
             for s in range(k):
                 ops.cell_fwd(xw[t], Hs[0][t], Cs[s][t], groups[s][1], durations_dev, t, out=outs[s][:, t],
                              out_batch_stride=T * H * W * Fh, save_gates=False, h_out=Hs[s][t + 1], c_out=Cs[s][t + 1],
-                             gates=Gs[s][t])
+                             gates=Gs[s][t] if keep else None)
                 if s > 0 and live is not None:
                     # a finished sample's state passes through; the kernel copied its RECURRENT input (group 0's h)
                     Hs[s][t + 1].copy_(torch.where(live, Hs[s][t + 1], Hs[s][t]))
@@ -688,6 +696,8 @@ def _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state):
         out, c, h = _WideSequenceFunction.apply(*args)
     else:
         class _Ctx:  # the forward alone; nothing is kept
+            forward_only = True
+
             def set_materialize_grads(self, _):
                 pass
         out, c, h = _WideSequenceFunction.forward(_Ctx(), *[a.detach() if torch.is_tensor(a) else a for a in args])
