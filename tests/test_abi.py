@@ -51,3 +51,42 @@ def test_upload_accepts_every_integer_and_float_dtype():
         assert t.dtype == torch.int32 and np.array_equal(t.numpy(), a.astype(np.int32))
     assert ops.upload(np.zeros([0], np.int32), "cpu").numel() == 0
     assert ops.upload([[1, 2], [3, 4]], "cpu").tolist() == [[1, 2], [3, 4]]
+
+
+def test_new_entry_points_reject_bad_arguments_on_the_host():
+    """Shapes without an instantiation, aliased state buffers, null pointers and sizes past a built-in limit come
+    back as ISG_EINVAL (-1) with a message, before any device call."""
+    lib = _lib.lib()
+    one = ctypes.c_void_p(4096)  # never dereferenced: every call below fails its argument checks first
+    two = ctypes.c_void_p(8192)
+    # first-layer and square encoder convolutions: only the instantiated tap / channel counts
+    assert lib.isg_conv_in_packed_elems(14, 32) > 0 and lib.isg_conv_in_packed_elems(5, 16) > 0
+    assert lib.isg_conv_in_packed_elems(7, 32) == -1 and lib.isg_conv_in_packed_elems(5, 24) == -1
+    assert lib.isg_conv_in_fwd(one, one, one, 1, 8, 8, 7, 32, 1, one, None) == -1
+    assert b"no instantiation" in lib.isg_last_error()
+    assert lib.isg_conv16_packed_elems(3) == 9 * 64 * 8 and lib.isg_conv16_packed_elems(4) == -1
+    assert lib.isg_conv16(one, one, None, 1, 8, 8, 4, 1, one, None) == -1
+    assert lib.isg_conv16(None, one, None, 1, 8, 8, 3, 1, one, None) == -1
+    assert lib.isg_conv32_wgrad(one, one, 0, 8, 8, 3, one, one, None) == -1
+    # fused backward step: shapes it has no kernel for, and the buffers that must not alias
+    assert lib.isg_convlstm_bwd_fused_supported(16, 16, 1, 2, 8, 8, 0) == 1
+    assert lib.isg_convlstm_bwd_fused_supported(48, 16, 1, 2, 8, 8, 2) == 1
+    assert lib.isg_convlstm_bwd_fused_supported(64, 16, 1, 2, 8, 8, 0) == 0   # 64 + 16 rows do not fit two row tiles
+    assert lib.isg_convlstm_bwd_fused_supported(16, 16, 0, 2, 8, 8, 0) == 0   # f32
+    assert lib.isg_convlstm_bwd_fused_supported(16, 16, 1, 2, 8, 8, 3) == 0   # more than two history frames
+
+    def fused(cs=16, dh_state=one, dh_prev=two, dc_state=one, dc_prev=two, mode=2, pool=1, above=one):
+        return lib.isg_convlstm_bwd_fused(one, one, one, above, 0, pool, dh_state, dc_state, one, one, one, 2, 8, 8, cs, cs, 16,
+                                          1, None, 0, None, 0, 0, None, dc_prev, dh_prev, None, 0, 0, 0, one, mode, None,
+                                          None)
+
+    assert fused(cs=64) == -1 and b"isg_convlstm_bwd_fused_supported" in lib.isg_last_error()
+    assert fused(dh_state=one, dh_prev=one) == -1 and b"alias" in lib.isg_last_error()
+    assert fused(dc_state=two, dc_prev=two) == -1
+    assert fused(mode=0) == -1 and b"workspace" in lib.isg_last_error()
+    assert fused(pool=3) == -1 and b"power of two" in lib.isg_last_error()
+    assert fused(above=None) == -1 and b"null" in lib.isg_last_error()
+    assert lib.isg_convlstm_bwd_fused_hist_bytes(4, 2) >= 4 * 2 * 9 * 64 * 2
+    # the allocation-free entry point refuses channel counts past its built-in scratch
+    assert lib.isg_relu_bwd_bias_static(one, one, 1024, 128, 1, one, one, None) == -1
+    assert b"64" in lib.isg_last_error()
