@@ -72,24 +72,32 @@ struct BwdParams {
     void* hist_dy;          // [B][hist][9][64] bf16, zeroed by the host: dY at the pixel each tap reaches from a point
 };
 
-template <int C0, int MT, int TR>
+// PIPE: three tiles in flight over two dY images (see the top of the file).  !PIPE: one dY image, every wave in the
+// same order (gate backward, store phase, phase B), two tiles in flight - what an 8-row tile of the two-row-tile
+// kernel can afford: its weight image alone is 54 - 72 KB.
+template <int C0, int MT, int TR, bool PIPE>
 struct FB {
     static constexpr int NPXH = (TR + 2) * HALO_W;       // halo tile pixels
     static constexpr int DY_PSTRIDE = NG * 2 + 16;       // padded pixel stride of the halo dY image
     static constexpr int DYH_BYTES = NPXH * DY_PSTRIDE;
+    static constexpr int NDY = PIPE ? 2 : 1;             // dY images
     static constexpr int RSTRIDE = 64;                   // 32 channels: one region row of the [x | h_prev] image
     static constexpr int IN_REGION = NPXH * RSTRIDE;
     static constexpr int IN_BYTES = MT * IN_REGION;
     static constexpr int NS = 9 * (NG / 16);             // k-steps of the data gradient
-    static constexpr int W_BYTES = NS * MT * 1024;
-    // two dY images: the gate backward of the next tile fills one while phase B reads the other
-    static constexpr int OFF_DYH = W_BYTES, OFF_IN = OFF_DYH + 2 * DYH_BYTES;
+    // Rows C0 + F .. 63 of the second row tile are padding whose results nobody stores: when they are the tile's
+    // upper 16 rows, only its lower 16 are kept in LDS (lanes of the upper rows read the lower rows' fragments).
+    static constexpr bool WCOMPACT = MT == 2 && TR == 8 && C0 + F_ <= 48;  // (the wave then owns both row tiles)
+    static constexpr int W1_STEP = WCOMPACT ? 512 : 1024;     // bytes per k-step of the second row tile
+    static constexpr int W_BYTES = NS * 1024 + (MT == 2 ? NS * W1_STEP : 0);
+    static constexpr int OFF_DYH = W_BYTES, OFF_IN = OFF_DYH + NDY * DYH_BYTES;
     static constexpr int LDS_BYTES = OFF_IN + IN_BYTES;
     static constexpr int NPW = (NPXH * 4 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (4 channels per item)
     static constexpr int NCH0 = C0 / 8, NCHT = NCH0 + 2;                    // 16-byte chunks of x / of [x | h_prev]
     static constexpr int NXP = (NPXH * NCHT + kBwdThreads - 1) / kBwdThreads;
     static constexpr int NSLOT = MT == 1 ? 3 : 5;        // (tap, row tile) pairs per wave in the weight gradient
-    static_assert(TR * MT == 8, "one data-gradient unit (tile row x row tile) per wave");
+    static constexpr int NMT = TR * MT / 8;              // row tiles of ONE tile row a wave takes in the data gradient
+    static_assert(TR * MT == 8 || (TR == 8 && MT == 2), "data-gradient units (tile row x row tile) per wave: 1 or 2");
     static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0, "input channels must fit the row tiles");
     static_assert(DYH_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -97,9 +105,9 @@ struct FB {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-template <int C0, int MT, int TR>
+template <int C0, int MT, int TR, bool PIPE>
 __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
-    using K = FB<C0, MT, TR>;
+    using K = FB<C0, MT, TR, PIPE>;
     using T = __bf16;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     (void)sizeof(s16x8);
@@ -114,7 +122,16 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     {  // weight image, once per workgroup; channels past the real ones of the [x | h_prev] image stay zero
         const uint4* src = static_cast<const uint4*>(p.wimg);
         uint4* dst = reinterpret_cast<uint4*>(lds_w);
-        for (int i = tid; i < K::W_BYTES / 16; i += kBwdThreads) dst[i] = src[i];
+        if constexpr (!K::WCOMPACT) {
+            for (int i = tid; i < K::W_BYTES / 16; i += kBwdThreads) dst[i] = src[i];
+        } else {
+            for (int i = tid; i < K::NS * 64; i += kBwdThreads) dst[i] = src[i];
+            // second row tile: fragment (k-step s, k half kg, row m < 16) -> 16-byte slot s * 32 + kg * 16 + m
+            for (int i = tid; i < K::NS * 32; i += kBwdThreads) {
+                const int sidx = i >> 5, kg = (i >> 4) & 1, m = i & 15;
+                dst[K::NS * 64 + i] = src[(K::NS + sidx) * 64 + kg * 32 + m];
+            }
+        }
         if constexpr (C0 + F_ < MT * 32) {
             for (int i = tid; i < K::IN_BYTES / 16; i += kBwdThreads)
                 reinterpret_cast<uint4*>(lds_in)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 
     struct Tile {
         int b, ty0, tx0;
-        bool valid;
+        int valid;  // (an int: a bool's padding bytes were copied through scratch memory)
     };
     // Every load below is issued unconditionally, from addresses clamped into the tensors (a tile past the end
     // re-reads the last one, a missing optional tensor reads the gate tensor instead) and its value is dropped
@@ -276,7 +293,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     }
 
     // data-gradient unit of this wave
-    const int dg_row = MT == 1 ? wave : wave >> 1, dg_mt = MT == 1 ? 0 : wave & 1;
+    // (one unit per wave: tile row x row tile; two when an 8-row tile has two row tiles: then both of the wave's row)
+    const int dg_row = (MT == 1 || K::NMT == 2) ? wave : wave >> 1;
+    const int dg_mt = (MT == 1 || K::NMT == 2) ? 0 : wave & 1;
 
     // ---------------- the tile pipeline ----------------
     // Three tiles are in flight.  Between two workgroup barriers a wave
@@ -418,15 +437,17 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // registers instead of vector register pairs)
         const unsigned dx_off = epixel_u * (unsigned)(p.dx_cstride * 2);
         // the running dx sum the epilogue adds to, requested ahead of the k-loop
-        uint2 pre[4];
+        uint2 pre[K::NMT][4];
         if (p.dx && p.dx_accumulate) {
 #pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
-                pre[a4] = make_uint2(0u, 0u);
-                if (cc0 < C0 && cc0 < p.dx_channels)
-                    pre[a4] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2)));
-            }
+            for (int u = 0; u < K::NMT; ++u)
+#pragma unroll
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
+                    pre[u][a4] = make_uint2(0u, 0u);
+                    if (cc0 < C0 && cc0 < p.dx_channels)
+                        pre[u][a4] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2)));
+                }
         }
         // (the weight gradient first: what the data gradient's epilogue waits for - the old dx values, and with
         // them every load requested before them - then has the whole of phase B to arrive)
@@ -476,43 +497,54 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #endif
         BSTAMP(s4);
         BSTAMP_ADD(4, s2, s4);  // weight-gradient k-loop
-        f32x16 acc;
+        // (a wave with two row tiles of its tile row takes them one after the other: both at once would need a second
+        // set of accumulators the kernel has no registers for; the dY fragments are read again instead)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int u = 0; u < K::NMT; ++u) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #ifndef ISG_BWD_NO_DGRAD  // diagnostic builds leave a phase out to see what the others take
-        {
-            const char* bb = lds_dyh + dyo + (dg_row * HALO_W + px_l) * K::DY_PSTRIDE + half * 16;
-            const char* aw = lds_w + (size_t)dg_mt * K::NS * 1024 + lane * 16;
-            bf16x8 a[2], b[2];
-            auto fetch = [&](int s, int slot) {
-                const int tap = s >> 2, qk = s & 3;
-                a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
-                b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
-            };
-            fetch(0, 0);
+            {
+                const char* bb = lds_dyh + dyo + (dg_row * HALO_W + px_l) * K::DY_PSTRIDE + half * 16;
+                // A fragments: one 16-byte slot per lane and k-step; the compact second row tile one slot per
+                // (k half, row % 16)
+                const bool second = K::NMT == 2 && u == 1;
+                const char* aw = !second ? lds_w + (size_t)dg_mt * K::NS * 1024 + lane * 16
+                                 : K::WCOMPACT ? lds_w + K::NS * 1024 + ((lane >> 5) * 16 + (lane & 15)) * 16
+                                               : lds_w + K::NS * 1024 + lane * 16;
+                const int astep = second ? K::W1_STEP : 1024;
+                bf16x8 a[2], b[2];
+                auto fetch = [&](int s, int slot) {
+                    const int tap = s >> 2, qk = s & 3;
+                    a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * astep);
+                    b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
+                };
+                fetch(0, 0);
 #pragma unroll
-            for (int s = 0; s < K::NS; ++s) {
-                if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < K::NS; ++s) {
+                    if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
 #endif
-        if (e_in) {
+            if (e_in) {
 #pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
-                const int cc0 = 32 * dg_mt + 8 * a4 + 4 * half;
-                if (cc0 < C0) {
-                    if (p.dx && cc0 < p.dx_channels) {
-                        if (p.dx_accumulate) {
-                            v[0] += bf_lo(pre[a4].x), v[1] += bf_hi(pre[a4].x);
-                            v[2] += bf_lo(pre[a4].y), v[3] += bf_hi(pre[a4].y);
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
+                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
+                    if (cc0 < C0) {
+                        if (p.dx && cc0 < p.dx_channels) {
+                            if (p.dx_accumulate) {
+                                v[0] += bf_lo(pre[u][a4].x), v[1] += bf_hi(pre[u][a4].x);
+                                v[2] += bf_lo(pre[u][a4].y), v[3] += bf_hi(pre[u][a4].y);
+                            }
+                            store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
                         }
-                        store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
+                    } else if (cc0 < C0 + F_) {
+                        store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)((cc0 - C0) * 2))), v);
                     }
-                } else if (cc0 < C0 + F_) {
-                    store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)((cc0 - C0) * 2))), v);
                 }
             }
         }
@@ -527,27 +559,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     (std::make_integer_sequence<int, K::NPW>{});
     [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(cur, std::integral_constant<int, I>{}), ...); }
     (std::make_integer_sequence<int, K::NXP>{});
-    gate_backward(cur, nxt, lds_dyh);  // dY image 0 of tile 0; the operands of tile 1 requested
-    bool cur_live = m_live;
+    bool cur_live = false;
     int cur_buf = 0;                // dY image of tile `cur`
-    const bool m_first = wave < 4;  // one wave of each kind per SIMD (waves w and w + 4 share one)
-
-    // The join between two intervals: every wave is done with the LDS images of tile `cur`; the next tile
-    // becomes `cur`, its [x | h_prev] chunks go to LDS and those of the tile after it are requested.
-    Tile nxt2 = nxt;
-    auto join = [&]() __attribute__((always_inline)) {
-        BSTAMP(s6);
-        __syncthreads();
-        BSTAMP(s7);
-        cur = nxt, nxt = nxt2, cur_live = m_live, cur_buf ^= 1;
-        store_phase(cur, cur_live, nxt);
-        BSTAMP(s8);
-        __syncthreads();
-        BSTAMP(s9);
-        BSTAMP_ADD(5, s6, s7);  // barrier after phase B / the gate backward
-        BSTAMP_ADD(0, s7, s8);  // store phase
-        BSTAMP_ADD(1, s8, s9);  // barrier after it
-    };
     auto run_b = [&]() __attribute__((always_inline)) {
         if (cur_live) {
             const int egy = cur.ty0 + dg_row, egx = cur.tx0 + px_l;
@@ -558,23 +571,65 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     };
 
     BSTAMP(t_begin);
-    // Both orders out of ONE copy of each phase (two copies cost more registers than there are): the loop body is
-    // gate backward -> phase B for every wave, and what differs is where the join falls.  Waves 0-3 join after
-    // phase B: their interval is [gate backward of tile k + 1, phase B of tile k].  Waves 4-7 join between the
-    // two, so that phase B of a pass already works on tile k + 1: their interval is [phase B of tile k, gate
-    // backward of tile k + 1].  Every wave passes the same number of barriers.
-    store_phase(cur, cur_live, nxt);
-    __syncthreads();  // (also the weight image)
-    if (!m_first) run_b();
-    for (int k = 0; k < n_iter; ++k) {
-        nxt2 = tile_ref(k + 2);
-        BSTAMP(s1c);
-        gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ 1) * K::DYH_BYTES);
-        BSTAMP(s1d);
-        BSTAMP_ADD(2, s1c, s1d);  // gate backward of the next tile
-        if (m_first) run_b();
-        join();
+    if constexpr (PIPE) {
+        gate_backward(cur, nxt, lds_dyh);  // dY image 0 of tile 0; the operands of tile 1 requested
+        cur_live = m_live;
+        const bool m_first = wave < 4;  // one wave of each kind per SIMD (waves w and w + 4 share one)
+
+        // The join between two intervals: every wave is done with the LDS images of tile `cur`; the next tile
+        // becomes `cur`, its [x | h_prev] chunks go to LDS and those of the tile after it are requested.
+        Tile nxt2 = nxt;
+        auto join = [&]() __attribute__((always_inline)) {
+            BSTAMP(s6);
+            __syncthreads();
+            BSTAMP(s7);
+            cur = nxt, nxt = nxt2, cur_live = m_live, cur_buf ^= 1;
+            store_phase(cur, cur_live, nxt);
+            BSTAMP(s8);
+            __syncthreads();
+            BSTAMP(s9);
+            BSTAMP_ADD(5, s6, s7);  // barrier after phase B / the gate backward
+            BSTAMP_ADD(0, s7, s8);  // store phase
+            BSTAMP_ADD(1, s8, s9);  // barrier after it
+        };
+        // Both orders out of ONE copy of the gate backward (two copies cost more registers than there are): the
+        // loop body is gate backward -> phase B for every wave, and what differs is where the join falls.  Waves
+        // 0-3 join after phase B: their interval is [gate backward of tile k + 1, phase B of tile k].  Waves 4-7
+        // join between the two, so that phase B of a pass already works on tile k + 1: their interval is [phase B
+        // of tile k, gate backward of tile k + 1].  Every wave passes the same number of barriers.
+        store_phase(cur, cur_live, nxt);
+        __syncthreads();  // (also the weight image)
         if (!m_first) run_b();
+        for (int k = 0; k < n_iter; ++k) {
+            nxt2 = tile_ref(k + 2);
+            BSTAMP(s1c);
+            gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ 1) * K::DYH_BYTES);
+            BSTAMP(s1d);
+            BSTAMP_ADD(2, s1c, s1d);  // gate backward of the next tile
+            if (m_first) run_b();
+            join();
+            if (!m_first) run_b();
+        }
+    } else {
+        for (int k = 0; k < n_iter; ++k) {
+            BSTAMP(s0);
+            gate_backward(cur, nxt, lds_dyh);  // this tile's dY; the operands of the next tile requested
+            cur_live = m_live;
+            BSTAMP(s1);
+            store_phase(cur, cur_live, nxt);
+            BSTAMP(s2);
+            __syncthreads();  // (first pass: also the weight image)
+            BSTAMP(s3);
+            run_b();
+            BSTAMP(s6);
+            __syncthreads();
+            BSTAMP(s7);
+            BSTAMP_ADD(2, s0, s1);  // gate backward
+            BSTAMP_ADD(0, s1, s2);  // store phase
+            BSTAMP_ADD(1, s2, s3);  // barrier after it
+            BSTAMP_ADD(5, s6, s7);  // barrier after phase B
+            cur = nxt, nxt = tile_ref(k + 2);
+        }
     }
 #ifdef ISG_STAMPS
     BSTAMP(t_end);
@@ -640,19 +695,19 @@ __global__ __launch_bounds__(NG) void hist_side_finish_kernel(const float* __res
     *dst = accumulate ? *dst + sum : sum;
 }
 
-template <int C0, int MT, int TR>
+template <int C0, int MT, int TR, bool PIPE>
 int launch_bwd(BwdParams p, int num_cus, hipStream_t stream) {
-    using K = FB<C0, MT, TR>;
+    using K = FB<C0, MT, TR, PIPE>;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TR - 1) / TR;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
     const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
     const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
     (void)num_cus;
-    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream, p);
     return isg::check_launch("convlstm_bwd_fused_kernel");
 }
 
@@ -737,9 +792,15 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
         hipError_t e = hipMemsetAsync(hist_scratch, 0, (size_t)hist_dy_bytes(B, hist), s);
         ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    int rc = Cs == 16   ? launch_bwd<16, 1, 8>(p, bwd_num_cus(), s)
-             : Cs == 32 ? launch_bwd<32, 2, 4>(p, bwd_num_cus(), s)
-                        : launch_bwd<48, 2, 4>(p, bwd_num_cus(), s);
+#ifdef ISG_BWD_L0_TR4  // diagnostic build: the 48-row kernel on pipelined 4-row tiles
+    int rc = Cs == 16   ? launch_bwd<16, 1, 8, true>(p, bwd_num_cus(), s)
+             : Cs == 32 ? launch_bwd<32, 2, 4, true>(p, bwd_num_cus(), s)
+                        : launch_bwd<48, 2, 4, true>(p, bwd_num_cus(), s);
+#else
+    int rc = Cs == 16   ? launch_bwd<16, 1, 8, true>(p, bwd_num_cus(), s)
+             : Cs == 32 ? launch_bwd<32, 2, 8, false>(p, bwd_num_cus(), s)
+                        : launch_bwd<48, 2, 4, true>(p, bwd_num_cus(), s);
+#endif
     if (rc != ISG_OK) return rc;
     if (hist > 0) {
         float* partial = reinterpret_cast<float*>(static_cast<char*>(hist_scratch) + hist_dy_bytes(B, hist));

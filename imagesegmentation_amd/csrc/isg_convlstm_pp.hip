@@ -889,8 +889,13 @@ namespace isgc {
 
 int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream_t stream) {
     if (mode == 0) {
-        if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, false>(p, num_cus, stream);
-        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, false>(p, num_cus, stream);
+#ifdef ISG_PP_EARLY_FWD  // diagnostic build: the forward cell with its tiles requested one phase earlier
+        constexpr bool kEarly = true;
+#else
+        constexpr bool kEarly = false;
+#endif
+        if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, kEarly>(p, num_cus, stream);
+        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, kEarly>(p, num_cus, stream);
         if (p.c0 == 48 && p.c1 == 16) return launch_pp<48, 16, 2, 0, false, 1>(p, num_cus, stream);
         return kNotSupported;
     }
