@@ -105,7 +105,8 @@ struct FB {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-template <int C0, int MT, int TR, bool PIPE>
+// ACC: dx is added to what the array holds (the static features' gradient over the steps of a sequence).
+template <int C0, int MT, int TR, bool PIPE, bool ACC>
 __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
     using K = FB<C0, MT, TR, PIPE>;
     using T = __bf16;
@@ -387,8 +388,13 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         }(std::make_integer_sequence<int, K::NPW>{});
     };
 
-    // Store phase of tile `c`: its [x | h_prev] chunks (in sx) into the LDS image, then the request for those of
-    // the tile after it.
+    // Store phase of tile `c`: its [x | h_prev] chunks (in sx) into the LDS image, then (pipelined schedule) the
+    // request for those of the tile after it.
+    auto request_x = [&](const Tile& r) __attribute__((always_inline)) {
+        x_inside = 0u;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(r, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, K::NXP>{});
+    };
     auto store_phase = [&](const Tile& c, bool live, const Tile& after) __attribute__((always_inline)) {
         if (live) {
             [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -421,9 +427,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
         }
-        x_inside = 0u;
-        [&]<int... I>(std::integer_sequence<int, I...>) { (load_x(after, std::integral_constant<int, I>{}), ...); }
-        (std::make_integer_sequence<int, K::NXP>{});
+        if constexpr (PIPE) request_x(after);
     };
 
 #ifdef ISG_STAMPS
@@ -437,16 +441,21 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // registers instead of vector register pairs)
         const unsigned dx_off = epixel_u * (unsigned)(p.dx_cstride * 2);
         // the running dx sum the epilogue adds to, requested ahead of the k-loop
+        // Requested by every lane of an accumulating launch, on every path (a lane whose channels lie past
+        // dx_channels re-reads the first bytes of dx and drops them): a load under a condition is one the compiler
+        // cannot count, and it then waits for everything in flight wherever the register comes up again.
+        constexpr bool accumulate = ACC;  // (the host picks the instantiation: p.dx != null and p.dx_accumulate)
+        const char* pre_base = static_cast<const char*>(p.dx);
         uint2 pre[K::NMT][4];
-        if (p.dx && p.dx_accumulate) {
+        if constexpr (ACC) {
 #pragma unroll
             for (int u = 0; u < K::NMT; ++u)
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
                     const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
-                    pre[u][a4] = make_uint2(0u, 0u);
-                    if (cc0 < C0 && cc0 < p.dx_channels)
-                        pre[u][a4] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2)));
+                    const bool has = cc0 < C0 && cc0 < p.dx_channels;
+                    if (32 * u + 8 * a4 < C0 || K::NMT == 1)  // (compile-time: row groups that can hold dx channels at all)
+                        pre[u][a4] = *reinterpret_cast<const uint2*>(pre_base + (size_t)(has ? dx_off + (unsigned)(cc0 * 2) : 0u));
                 }
         }
         // (the weight gradient first: what the data gradient's epilogue waits for - the old dx values, and with
@@ -529,19 +538,31 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
 #endif
+            // The old dx values are added to ALL accumulators before the first store goes out: a store between two
+            // of these uses would make the wait for the next old value also wait for that store's completion (the
+            // counter is in order), one memory round trip per 8 bytes of dx.
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                if (ACC && (32 * u + 8 * a4 < C0 || K::NMT == 1)) {
+                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
+                    const bool has = accumulate && cc0 < C0 && cc0 < p.dx_channels;
+                    const uint2 o = pre[u][a4];
+                    acc[4 * a4] += has ? bf_lo(o.x) : 0.0f, acc[4 * a4 + 1] += has ? bf_hi(o.x) : 0.0f;
+                    acc[4 * a4 + 2] += has ? bf_lo(o.y) : 0.0f, acc[4 * a4 + 3] += has ? bf_hi(o.y) : 0.0f;
+                }
+            }
+            // (the sums exist HERE, in registers: without this the additions sink into the conditional stores below)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
+            __builtin_amdgcn_sched_barrier(0);
             if (e_in) {
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
                     float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
                     const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
                     if (cc0 < C0) {
-                        if (p.dx && cc0 < p.dx_channels) {
-                            if (p.dx_accumulate) {
-                                v[0] += bf_lo(pre[u][a4].x), v[1] += bf_hi(pre[u][a4].x);
-                                v[2] += bf_lo(pre[u][a4].y), v[3] += bf_hi(pre[u][a4].y);
-                            }
+                        if (p.dx && cc0 < p.dx_channels)
                             store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
-                        }
                     } else if (cc0 < C0 + F_) {
                         store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)((cc0 - C0) * 2))), v);
                     }
@@ -621,6 +642,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             __syncthreads();  // (first pass: also the weight image)
             BSTAMP(s3);
             run_b();
+            // (requested here, not in the store phase: phase B is where registers are shortest, and the chunks still
+            // have the next tile's gate backward to arrive)
+            request_x(nxt);
             BSTAMP(s6);
             __syncthreads();
             BSTAMP(s7);
@@ -695,20 +719,27 @@ __global__ __launch_bounds__(NG) void hist_side_finish_kernel(const float* __res
     *dst = accumulate ? *dst + sum : sum;
 }
 
-template <int C0, int MT, int TR, bool PIPE>
-int launch_bwd(BwdParams p, int num_cus, hipStream_t stream) {
+template <int C0, int MT, int TR, bool PIPE, bool ACC>
+int launch_bwd_acc(BwdParams p, hipStream_t stream) {
     using K = FB<C0, MT, TR, PIPE>;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TR - 1) / TR;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
     const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
     const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
-    (void)num_cus;
-    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
+                       p);
     return isg::check_launch("convlstm_bwd_fused_kernel");
+}
+
+template <int C0, int MT, int TR, bool PIPE>
+int launch_bwd(const BwdParams& p, int num_cus, hipStream_t stream) {
+    (void)num_cus;
+    return p.dx != nullptr && p.dx_accumulate ? launch_bwd_acc<C0, MT, TR, PIPE, true>(p, stream)
+                                             : launch_bwd_acc<C0, MT, TR, PIPE, false>(p, stream);
 }
 
 int bwd_num_cus() {
