@@ -305,6 +305,10 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             return;
         }
+        // Everything this wave has requested is waited for HERE, ahead of the first store (s_waitcnt vmcnt(0); the
+        // staged tile was needed by the LDS writes just before anyway): the memory counter is in order, so a wait
+        // for a prefetched operand placed behind a store would also wait for that store to complete.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         // History taps touch the 3 x 3 pixels around a history point: a wave whose rows are nowhere near one
         // (nearly every wave) skips them on a scalar test.
         const int hpx[2] = {p.hist > 0 ? r.hp[0] : -1, p.hist > 1 ? r.hp[2] : -1};
