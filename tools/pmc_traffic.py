@@ -46,7 +46,7 @@ def per_label(rows):
             assert len(values) == CALLS * per_call, (label, len(values))
             out[label] = sum(values) / CALLS
 
-    put("bwd_fused[layer0 C=33]", pick("convlstm_bwd_fused_kernel<32, 2, 4"))
+    put("bwd_fused[layer0 C=33]", pick("convlstm_bwd_fused_kernel<32, 2, 8"))
     put("bwd_fused[layer1 C=16]", pick("convlstm_bwd_fused_kernel<16, 1, 8"))
     put("cell_fwd[layer0 C=33]", pick("conv3x3_pp_kernel<32, 16, 2, 0"))
     put("cell_fwd[layer1 C=16]", pick("conv3x3_pp_kernel<16, 16, 2, 0"))
