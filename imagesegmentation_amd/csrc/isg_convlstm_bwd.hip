@@ -11,9 +11,11 @@
 //     transposing LDS reads; the accumulators stay in registers over all tiles and leave as one slab per
 //     workgroup), then the data gradient (each wave one tile row x one 32-row tile of input channels, weight
 //     image resident in LDS) with its dx / dh_prev stores.
-// Three tiles are in flight: there are TWO dY images, so the gate backward of tile n + 1 (vector ALU) runs while
-// phase B of tile n (matrix pipe) reads the other image, in opposite order on the two waves of every SIMD, and
-// the operands of tile n + 2 are requested into each staging register as the gate backward frees it.
+// Pipelined schedule (PIPE): three tiles are in flight - there are TWO dY images, so the gate backward of tile
+// n + 1 (vector ALU) runs while phase B of tile n (matrix pipe) reads the other image, in opposite order on the two
+// waves of every SIMD, and the operands of tile n + 2 are requested into each staging register as the gate
+// backward frees it.  The 48-row kernel (two row tiles, a 54 - 72 KB weight image) has LDS for one dY image on
+// 8-row tiles only: there every wave runs the three parts in order, with the next tile's operands in flight.
 // What bounds it: the vector ALU (about 1,300 instructions per wave and tile, two thirds of them unpacking,
 // addressing and converting around the gate arithmetic) with ~650 - 900 bytes per pixel in flight behind it.
 #include <utility>
