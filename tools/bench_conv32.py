@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic: the square encoder convolutions launched alone at the benchmark shape (B=64, 224 x 224).
+ISG_LIBRARY selects a variant library.  usage: bench_conv32.py [repeats]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from imagesegmentation_amd import _lib
+    if os.environ.get("ISG_LIBRARY"):
+        _lib.LIB_PATH = os.environ["ISG_LIBRARY"]
+    from imagesegmentation_amd import ops
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dev = torch.device("cuda:0")
+    out = []
+    for c in (32, 16):
+        x = torch.randn([64, 224, 224, c], device=dev).to(torch.bfloat16)
+        for ks in (5, 3):
+            w = ops.conv32_pack(torch.randn([ks, ks, c, c], device=dev) * 0.05)
+            b = torch.zeros([c], device=dev)
+            for _ in range(3):
+                ops.conv32(x, w, b, ks, True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                ops.conv32(x, w, b, ks, True)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append("C=%d %dx%d %.4f ms" % (c, ks, ks, e0.elapsed_time(e1) / n))
+    print(os.environ.get("ISG_LIBRARY", "default"), " | ".join(out))
+
+
+if __name__ == "__main__":
+    main()
