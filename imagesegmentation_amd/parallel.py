@@ -6,8 +6,20 @@ ranks, every rank holds the full weights, and the only exchange per step is ONE 
 flat float32 gradient bucket (the reference's closest analogue is the parameter-server push/pull of
 polyrl/a3c/a3c.py:251-258).  The rasteriser / IoU path has no exchange at all.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _collectives_on(group=None):
+    """Whether the gradient exchange is issued: more than one rank - or ISG_FORCE_COLLECTIVES=1 with an initialised
+    process group of ONE rank, which sends every collective of the multi-rank path through the library (a
+    one-rank all-reduce is the identity): the way to run the RCCL calls, the early-tail hook and their stream
+    ordering on a machine with a single GPU."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("ISG_FORCE_COLLECTIVES"))
 
 
 def world_size(group=None):
@@ -39,11 +51,10 @@ def allreduce_gradients_(flat, group=None, average=True):
     ``average=True`` matches a loss that is a mean over the GLOBAL batch when every rank holds an equal
     share (reference polyrnn/Model.py:98-100); ``average=False`` matches gradients that the reference
     sums over episodes (polyrl/ReinforceOverfitExperiment.py:168-176)."""
-    world = world_size(group)
-    if world > 1:
+    if _collectives_on(group):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
-            flat.div_(world)
+            flat.div_(world_size(group))
     return flat
 
 
@@ -72,7 +83,7 @@ class EarlyTailReduce:
         self.armed, self._seen, self._work = True, 0, None
 
     def _on_grad(self, _param):
-        if not self.armed or world_size(self.group) == 1:
+        if not self.armed or not _collectives_on(self.group):
             return
         self._seen += 1
         if self._seen == self._n:
@@ -84,7 +95,7 @@ class EarlyTailReduce:
         was_armed, self.armed = self.armed, False
         work, self._work = self._work, None
         world = world_size(self.group)
-        if world == 1:
+        if not _collectives_on(self.group):
             return self.flat
         if not was_armed or work is None:
             return allreduce_gradients_(self.flat, self.group, average)
@@ -98,7 +109,7 @@ class EarlyTailReduce:
 
 def allreduce_max(value, device, group=None):
     """Max of a python float over ranks (timing)."""
-    if world_size(group) == 1:
+    if not _collectives_on(group):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
