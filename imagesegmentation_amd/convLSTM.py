@@ -400,6 +400,53 @@ class RecurrentStepper:
         return self.out
 
 
+class WideStepper:
+    """One cell of 16 k filters advanced one step at a time, without autograd (acting in a rollout): the state stays
+    split by 16-filter group in ping-pong buffers and the joint input [x | h[16:]] in one buffer across steps, so a
+    step is one copy of x, one of each further group's h, k fused cell launches and the join of the k outputs -
+    where a ``dynamic_rnn`` call per step would split and rejoin the whole state every time."""
+
+    def __init__(self, cell, batch, device, initial_state=None):
+        self.cell = cell
+        Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
+        H, W = cell._shape
+        self.k = F // Fh
+        self.C = int(cell.input_to_state_kernel.shape[2])
+        self.groups = _wide_groups(cell, self.C)
+        cs = self.groups[0][1].cs
+        self.xw = torch.zeros([batch, H, W, cs], dtype=dt, device=device)
+        self.H = [torch.zeros([2, batch, H, W, Fh], dtype=dt, device=device) for _ in range(self.k)]
+        self.Cst = [torch.zeros([2, batch, H, W, Fh], dtype=torch.float32, device=device) for _ in range(self.k)]
+        self.outs = [torch.empty([batch, 1, H, W, Fh], dtype=dt, device=device) for _ in range(self.k)]
+        self.cur = 0
+        self._stride = H * W * Fh
+        if initial_state is not None:
+            c0, h0 = initial_state
+            for g in range(self.k):
+                self.Cst[g][0].copy_(c0[..., Fh * g:Fh * g + Fh])
+                self.H[g][0].copy_(h0[..., Fh * g:Fh * g + Fh])
+
+    @property
+    def state(self):
+        """(c, h) of the whole cell, joined (a copy)."""
+        cur = self.cur
+        return LSTMStateTuple(torch.cat([c[cur] for c in self.Cst], dim=-1), torch.cat([h[cur] for h in self.H], dim=-1))
+
+    def step(self, x):
+        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step."""
+        Fh, C = ops.F_HIDDEN, self.C
+        cur, nxt = self.cur, 1 - self.cur
+        groups = _wide_groups(self.cell, C)  # (re-packed when the weights have changed)
+        self.xw[..., :C] = x
+        for g in range(1, self.k):
+            self.xw[..., C + Fh * (g - 1):C + Fh * g] = self.H[g][cur]
+        for g in range(self.k):
+            ops.cell_fwd(self.xw, self.H[0][cur], self.Cst[g][cur], groups[g][1], None, 0, out=self.outs[g],
+                         out_batch_stride=self._stride, save_gates=False, h_out=self.H[g][nxt], c_out=self.Cst[g][nxt])
+        self.cur = nxt
+        return torch.cat([o[:, 0] for o in self.outs], dim=-1)
+
+
 class _SequenceFunction(torch.autograd.Function):
     """MultiRNNCell + dynamic_rnn as ONE autograd node: T*L fused cell launches forward, and the
     hand-written reverse sweep (pointwise, weight-gradient and data-gradient kernels) backward."""

@@ -26,7 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import parallel
-from ..convLSTM import ConvLSTMCell, LSTMStateTuple, dynamic_rnn, glorot_uniform_
+from ..convLSTM import ConvLSTMCell, LSTMStateTuple, WideStepper, dynamic_rnn, glorot_uniform_
 from ..optim import FlatAdam
 from ..polyrnn import decode
 from ..polyrnn.Model import conv2d_same_relu
@@ -183,6 +183,24 @@ class LSTMPolicy:
             a = decode.sample_rows(logits[:, 0].contiguous(), seed=self._seed * 1000003 + self._sample_calls)
         return a.long(), vf[:, 0], c2, h2
 
+    def stepper(self, num_envs):
+        """Recurrent state of ``num_envs`` environments for ``act_step``: kept on the device in the layout the cell
+        kernels use, from the zero state (reference polyrl/a3c/model.py:27-29)."""
+        return WideStepper(self.lstm, num_envs, self.device)
+
+    def act_step(self, ob, stepper):
+        """``act`` with the recurrent state held by ``stepper`` (advanced in place): (action index int64 [N],
+        value [N]).  Same arithmetic and the same sampling stream as ``act``."""
+        with torch.no_grad():
+            feats = self._encode(ob)
+            flat = stepper.step(feats).reshape(ob.shape[0], -1)
+            dt = flat.dtype
+            logits = torch.addmm(self.action_bias.to(dt), flat, self.action_kernel.to(dt)).float()
+            vf = torch.addmm(self.value_bias.to(dt), flat, self.value_kernel.to(dt)).float()[:, 0]
+            self._sample_calls += 1
+            a = decode.sample_rows(logits.contiguous(), seed=self._seed * 1000003 + self._sample_calls)
+        return a.long(), vf
+
     def value(self, ob, c, h):
         with torch.no_grad():
             return self.forward(ob[:, None], (c, h))[1][:, 0]
@@ -213,7 +231,8 @@ class A3C:
         N, T, P = env.num_envs, self.TIMESTEP_LIMIT, env.size
         dev = env.device
         state = env.reset(images=images, polygons=polygons)
-        c, h = pi.get_initial_features(N)
+        rec = pi.stepper(N) if pi.filters > 16 else None  # the recurrent state, or (c, h) through ``act``
+        c, h = pi.get_initial_features(N) if rec is None else (None, None)
         obs = torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev)
         actions = torch.zeros([N, T], dtype=torch.int64, device=dev)
         values = torch.zeros([N, T], dtype=torch.float32, device=dev)
@@ -224,7 +243,10 @@ class A3C:
             # its later steps fall outside its length
             active = ~env.done
             obs[:, t] = state
-            a, v, c, h = pi.act(state, c, h)
+            if rec is not None:
+                a, v = pi.act_step(state, rec)
+            else:
+                a, v, c, h = pi.act(state, c, h)
             actions[:, t], values[:, t] = a, v
             lengths += active.to(torch.int32)
             xy = torch.stack([a // P, a % P], dim=1)

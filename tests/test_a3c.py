@@ -129,3 +129,29 @@ def test_synchronous_update_runs_and_learns_value(end_token):
     assert trainer.local_steps == 2 and trainer.global_step > 0
     moved = sum(float((a - b).abs().sum()) for a, b in zip(before, trainer.network.var_list))
     assert moved > 0 and all(bool(torch.isfinite(v).all()) for v in trainer.network.var_list)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stepper_acting_equals_stateless_acting(dtype):
+    """``act_step`` (recurrent state kept split by filter group on the device) against ``act`` (state passed in and
+    out as whole tensors) over four steps: same actions from the same sampling stream, same values, same state."""
+    from imagesegmentation_amd.polyrl import a3c
+    dev = torch.device("cuda:0")
+    N, P = 5, 12
+    a = a3c.LSTMPolicy((P, P, 5), P * P, compute_dtype=dtype, device=dev, seed=4)
+    b = a3c.LSTMPolicy((P, P, 5), P * P, compute_dtype=dtype, device=dev, seed=4)
+    with torch.no_grad():
+        for pa, pb in zip(a.var_list, b.var_list):
+            pb.copy_(pa)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    obs = [torch.rand([N, P, P, 5], device=dev, generator=gen) for _ in range(4)]
+    c, h = a.get_initial_features(N)
+    rec = b.stepper(N)
+    for ob in obs:
+        act_a, v_a, c, h = a.act(ob, c, h)
+        act_b, v_b = b.act_step(ob, rec)
+        assert torch.equal(act_a, act_b)
+        assert torch.equal(v_a, v_b)
+    st = rec.state
+    assert torch.equal(st.c, c.to(st.c.dtype)) and torch.equal(st.h, h.to(st.h.dtype))
