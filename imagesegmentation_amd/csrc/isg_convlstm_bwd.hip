@@ -97,7 +97,13 @@ struct FB {
     static constexpr int NPW = (NPXH * 4 + kBwdThreads - 1) / kBwdThreads;  // gate-backward passes (4 channels per item)
     static constexpr int NCH0 = C0 / 8, NCHT = NCH0 + 2;                    // 16-byte chunks of x / of [x | h_prev]
     static constexpr int NXP = (NPXH * NCHT + kBwdThreads - 1) / kBwdThreads;
-    static constexpr int NSLOT = MT == 1 ? 3 : 5;        // (tap, row tile) pairs per wave in the weight gradient
+    // Weight-gradient output tiles (32 input-channel rows x 64 dY columns, one per wave slot and column half).  One
+    // row tile: 9 (taps).  Two row tiles: 18 (tap, row tile) pairs - or, when the second row tile holds only the 16
+    // channels of h_prev (HMERGE), 9 tiles of x rows + 5 tiles that stack the h rows of TWO taps (rows 0-15: tap
+    // 2 j, rows 16-31: tap 2 j + 1): 14 tiles instead of 18, no MFMA row spent on padding channels.
+    static constexpr bool HMERGE = MT == 2 && C0 + F_ <= 48;
+    static constexpr int NWT = MT == 1 ? 9 : HMERGE ? 14 : 18;
+    static constexpr int NSLOT = (NWT + 3) / 4;          // tiles per wave (4 wave pairs share them)
     static constexpr int NMT = TR * MT / 8;              // row tiles of ONE tile row a wave takes in the data gradient
     static_assert(TR * MT == 8 || (TR == 8 && MT == 2), "data-gradient units (tile row x row tile) per wave: 1 or 2");
     static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0, "input channels must fit the row tiles");
@@ -265,12 +271,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 
     // ---- weight-gradient work of this wave: a group of (tap, row tile) pairs x one 32-column half of dY ----
     const int wg_n = wave & 1, wg_grp = wave >> 1;
-    int wg_first, wg_cnt;
-    if constexpr (MT == 1) {
-        wg_first = wg_grp == 0 ? 0 : 2 * wg_grp + 1, wg_cnt = wg_grp == 0 ? 3 : 2;  // {0,1,2} {3,4} {5,6} {7,8}
-    } else {
-        wg_first = wg_grp < 2 ? 5 * wg_grp : 10 + 4 * (wg_grp - 2), wg_cnt = wg_grp < 2 ? 5 : 4;  // 5 + 5 + 4 + 4 of 18
-    }
+    // the tiles are dealt to the 4 wave pairs in runs: the first NWT % 4 pairs take one more
+    constexpr int kBase = K::NWT / 4, kExtra = K::NWT % 4;
+    const int wg_first = wg_grp * kBase + min(wg_grp, kExtra), wg_cnt = kBase + (wg_grp < kExtra ? 1 : 0);
     const bool wg_full = wg_cnt == K::NSLOT;  // the last slot is used by the larger groups only
     f32x16 wacc[K::NSLOT];
 #pragma unroll
@@ -288,14 +291,23 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         wg_dy = lds_dyh + (HALO_W + 1 + lane_px) * K::DY_PSTRIDE + wg_n * 64 + csub * 2;
 #pragma unroll
         for (int i = 0; i < K::NSLOT; ++i) {
-            const int pair = wg_first + min(i, wg_cnt - 1);
-            const int tap = MT == 1 ? pair : pair >> 1, mt = MT == 1 ? 0 : pair & 1;
+            const int idx = wg_first + min(i, wg_cnt - 1);
+            int tap, mt, chan;
+            if constexpr (K::HMERGE) {
+                // tiles 0-8: x rows of tap idx; tiles 9-13: h rows of taps 2 j (this lane's rows 0-15) and 2 j + 1
+                // (rows 16-31; the ninth tap has no partner: its upper rows repeat it and are dropped at the end)
+                const bool htile = idx >= 9;
+                tap = htile ? min(2 * (idx - 9) + (g16 & 1), 8) : idx;
+                mt = htile ? 1 : 0;
+                chan = htile ? 4 * (li & 3) : csub;
+            } else {
+                tap = MT == 1 ? idx : idx >> 1, mt = MT == 1 ? 0 : idx & 1, chan = csub;
+            }
             const int dy = tap / 3, dx = tap - dy * 3;
-            wg_in[i] = lds_in + mt * K::IN_REGION + (dy * HALO_W + dx + lane_px) * K::RSTRIDE + csub * 2;
+            wg_in[i] = lds_in + mt * K::IN_REGION + (dy * HALO_W + dx + lane_px) * K::RSTRIDE + chan * 2;
         }
     }
 
-    // data-gradient unit of this wave
     // (one unit per wave: tile row x row tile; two when an 8-row tile has two row tiles: then both of the wave's row)
     const int dg_row = (MT == 1 || K::NMT == 2) ? wave : wave >> 1;
     const int dg_mt = (MT == 1 || K::NMT == 2) ? 0 : wave & 1;
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             // k-step = 16 consecutive pixels of a tile row.  Both operands come out of pixel-major LDS images
             // through the transposing read; every address is this lane's fixed base plus a compile-time
             // offset, and the fragments of the next k-step are requested before this one's MFMAs.
-            constexpr int NBUF = MT == 1 ? 2 : 1;  // the two-row-tile kernel has no registers for a second set
+            constexpr int NBUF = (MT == 1 || K::HMERGE) ? 2 : 1;  // (the 5-slot kernel has no registers for a second set)
             bf16x8 bq[NBUF], aq[NBUF][K::NSLOT];
             auto tr_pair = [](const char* a0, auto stride) {  // 8 consecutive pixels of one k-step half
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
@@ -670,13 +682,22 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #pragma unroll
     for (int i = 0; i < K::NSLOT; ++i) {
         if (i < wg_cnt) {
-            const int pair = wg_first + i;
-            const int tap = MT == 1 ? pair : pair >> 1, mt = MT == 1 ? 0 : pair & 1;
+            const int idx = wg_first + i;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int cc = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * wg_n + (lane & 31);
-                *dst = p.slab_accumulate ? *dst + wacc[i][reg] : wacc[i][reg];
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // row of the 32-row tile
+                int tap, cc;
+                if constexpr (K::HMERGE) {
+                    const bool htile = idx >= 9;
+                    tap = htile ? 2 * (idx - 9) + (row >> 4) : idx;
+                    cc = htile ? 32 + (row & 15) : row;
+                } else {
+                    tap = MT == 1 ? idx : idx >> 1, cc = (MT == 1 ? 0 : 32 * (idx & 1)) + row;
+                }
+                if (tap < 9) {
+                    float* dst = slab + ((size_t)tap * (MT * 32) + cc) * NG + 32 * wg_n + (lane & 31);
+                    *dst = p.slab_accumulate ? *dst + wacc[i][reg] : wacc[i][reg];
+                }
             }
         }
     }
