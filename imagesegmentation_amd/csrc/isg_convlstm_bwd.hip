@@ -449,7 +449,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #endif
 
     // phase B of tile `c`: data gradient of this wave's tile row (+ its stores), then the weight gradient
-    auto phase_b = [&](int dyo, bool e_in, unsigned epixel_u) __attribute__((always_inline)) {
+    auto phase_b = [&](int dyo, bool e_in, unsigned epixel_u, int tb, int ty0, int tx0) __attribute__((always_inline)) {
+        (void)tb, (void)ty0, (void)tx0;
         BSTAMP(s2);
         // (32-bit byte offsets from the tensors' bases, as everywhere in this kernel: the bases then stay in scalar
         // registers instead of vector register pairs)
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // (a wave with two row tiles of its tile row takes them one after the other: both at once would need a second
         // set of accumulators the kernel has no registers for; the dY fragments are read again instead)
 #pragma unroll
-        for (int u = 0; u < K::NMT; ++u) {
+        for (int u = 0; u < (K::WCOMPACT ? 1 : K::NMT); ++u) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -583,8 +584,54 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
         }
+        if constexpr (K::WCOMPACT) {
+            // The second row tile holds 16 real rows (h_prev's channels): 16 x 16 x 32 MFMAs, two per 32-deep k-step
+            // (pixels 0-15 and 16-31 of the tile row), half the matrix-pipe time of a 32-row tile that is half
+            // padding.  The compact weight image is already in this instruction's A layout: lane l reads 16 bytes
+            // at l * 16 of each 1 KB k-step (row l % 16, k = 8 (l / 16) .. + 7).
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 acc2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) acc2[hh] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int l16 = lane & 15, kb = lane >> 4;
+#ifndef ISG_BWD_NO_DGRAD
+            {
+                const char* bb = lds_dyh + dyo + (dg_row * HALO_W + l16) * K::DY_PSTRIDE + kb * 16;
+                const char* aw = lds_w + K::NS * 1024 + lane * 16;
+                bf16x8 a[2], b[2][2];
+                auto fetch = [&](int s32, int slot) {
+                    const int tap = s32 >> 1;
+                    a[slot] = *reinterpret_cast<const bf16x8*>(aw + s32 * 1024);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        b[slot][hh] = *reinterpret_cast<const bf16x8*>(
+                            bb + ((tap / 3) * HALO_W + (tap % 3) + 16 * hh) * K::DY_PSTRIDE + (s32 & 1) * 64);
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int s32 = 0; s32 < K::NS / 2; ++s32) {
+                    if (s32 + 1 < K::NS / 2) fetch(s32 + 1, (s32 + 1) & 1);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        acc2[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s32 & 1], b[s32 & 1][hh], acc2[hh], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#endif
+            // lane l: pixel 16 hh + l % 16 of the tile row, h_prev channels 4 (l / 16) .. + 3
+            const int gy2 = ty0 + dg_row;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int gx2 = tx0 + 16 * hh + l16;
+                if (gy2 < p.H && gx2 < p.W) {
+                    const unsigned pixel = (unsigned)((tb * p.H + gy2) * p.W + gx2);
+                    float v[4] = {acc2[hh][0], acc2[hh][1], acc2[hh][2], acc2[hh][3]};
+                    store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(pixel * (unsigned)(F_ * 2) + (unsigned)(kb * 8))), v);
+                }
+            }
+        }
         BSTAMP(s5);
-        BSTAMP_ADD(3, s4, s5);  // data gradient: k-loop and stores
+        BSTAMP_ADD(3, s4, s5);  // data gradient: k-loops and stores
     };
 
     Tile cur = tile_ref(0), nxt = tile_ref(1);
@@ -601,7 +648,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             const int egy = cur.ty0 + dg_row, egx = cur.tx0 + px_l;
             const bool e_in = egy < p.H && egx < p.W;
             const unsigned epixel = (unsigned)((cur.b * p.H + min(egy, p.H - 1)) * p.W + min(egx, p.W - 1));
-            phase_b(cur_buf * K::DYH_BYTES, e_in, epixel);
+            phase_b(cur_buf * K::DYH_BYTES, e_in, epixel, cur.b, cur.ty0, cur.tx0);
         }
     };
 
