@@ -54,11 +54,11 @@ SIGNATURES = {
     "isg_convlstm_packed_elems": (_ll, [_int, _int, _int]),
     "isg_convlstm_pack_weights": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
-                                     _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
+                                     _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _int, _vp]),
     "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),
     "isg_convlstm_pooled_fwd_supported": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
     "isg_convlstm_cell_fwd_pooled": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
-                                            _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _vp, _ll, _vp]),
+                                            _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _int, _vp, _ll, _vp]),
     "isg_convlstm_pointwise_bwd": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _int, _int, _int, _int, _int, _int,
                                           _vp, _int, _vp, _vp, _vp]),
     "isg_convlstm_dgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _int, _int, _vp,
@@ -68,7 +68,7 @@ SIGNATURES = {
                                   _vp, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_bwd_fused_supported": (_int, [_int, _int, _int, _int, _int, _int, _int]),
     "isg_convlstm_bwd_fused_hist_bytes": (_ll, [_int, _int]),
-    "isg_convlstm_bwd_fused": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
+    "isg_convlstm_bwd_fused": (_int, [_vp, _vp, _ll, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                       _int, _int, _vp, _int, _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
                                       _int, _vp, _vp]),
     "isg_convlstm_wgrad_finish": (_int, [_vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),

@@ -318,7 +318,11 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
         Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
         Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=torch.float32, device=dev).unbind(0)))
-    Gs = [torch.empty([T, B, H, W, F, 4], dtype=dt, device=dev) for _ in range(L)] if save else None
+    # What a layer keeps for backward: the backward factors where the fused backward step exists for its shape
+    # (all that kernel reads of the forward pass), else the gate activations for the three-kernel backward.
+    layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W) else ops.SAVE_GATES for l in range(L)]
+    Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, layouts[l]), dtype=dt, device=dev) for l in range(L)] \
+        if save else None
     # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
     fused_pool = pool > 1 and ops.pooled_fwd_supported(packed[L - 1], B, H, W, pool)
     oh, ow = (H // pool, W // pool) if fused_pool else (H, W)
@@ -335,7 +339,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
             ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
                          out=out[:, t] if top and not fused_pool else None, out_batch_stride=T * H * W * F,
                          save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
-                         hist_points=seq.points(t) if l == 0 else None,
+                         save_layout=layouts[l], hist_points=seq.points(t) if l == 0 else None,
                          pool_out=out[:, t] if top and fused_pool else None, pool_batch_stride=T * oh * ow * F,
                          pool=pool)
             x = Hs[l][nxt]
@@ -346,7 +350,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         final = [(Cs[l][0].clone(), Hs[l][0].clone()) for l in range(L)]
     else:
         final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
-    return out, final, (Hs, Cs, Gs, packed)
+    return out, final, (Hs, Cs, Gs, packed, layouts)
 
 
 class RecurrentStepper:
@@ -457,10 +461,10 @@ class _SequenceFunction(torch.autograd.Function):
         cells = list(multi.cells)
         L = len(cells)
         init_state = [(tensors[1 + 2 * l], tensors[2 + 2 * l]) for l in range(L)]
-        out, final, (Hs, Cs, Gs, packed) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, True,
-                                                                 pool)
+        out, final, (Hs, Cs, Gs, packed, layouts) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state,
+                                                                          True, pool)
         ctx.multi, ctx.seq, ctx.durations_dev, ctx.t_run = multi, seq, durations_dev, t_run
-        ctx.saved = (Hs, Cs, Gs, packed)
+        ctx.saved = (Hs, Cs, Gs, packed, layouts)
         ctx.in_dtype = tensors[0].dtype
         ctx.pool = pool
         ctx.state_dtypes = [(None if c is None else c.dtype, None if h is None else h.dtype) for c, h in init_state]
@@ -476,7 +480,7 @@ class _SequenceFunction(torch.autograd.Function):
         cells = list(ctx.multi.cells)
         L = len(cells)
         seq, durations_dev, t_run = ctx.seq, ctx.durations_dev, ctx.t_run
-        Hs, Cs, Gs, packed = ctx.saved
+        Hs, Cs, Gs, packed, layouts = ctx.saved
         dt = cells[0].compute_dtype
         B, H, W, F, T = seq.B, seq.H, seq.W, cells[0]._filters, seq.T
         dev = Hs[0][0].device
@@ -512,7 +516,7 @@ class _SequenceFunction(torch.autograd.Function):
         slabs = [ops.wgrad_workspace(packed[l].cs, F, dev, cached=False) for l in range(L)]
         # One launch per (step, layer) where the fused backward kernel exists (bf16): it reads the incoming state
         # gradients of neighbouring tiles' border pixels, so they alternate between two buffers per layer.
-        fused = [ops.bwd_fused_supported(packed[l], B, H, W) for l in range(L)]
+        fused = [layouts[l] == ops.SAVE_FACTORS for l in range(L)]
         dc_next = [torch.empty_like(dc_state[l]) if fused[l] else None for l in range(L)]
         dh_next = [torch.empty_like(dh_state[l]) if fused[l] else None for l in range(L)]
         for t in reversed(range(t_run)):
@@ -535,7 +539,7 @@ class _SequenceFunction(torch.autograd.Function):
                     raise NotImplementedError("static feature channels must be a multiple of 4")
                 pts = seq.points(t) if l == 0 else None
                 if fused[l]:
-                    ops.bwd_fused(Gs[l][t], Cs[l][t], Cs[l][t + 1], above, stride, dh_state[l], dc_state[l], x_in,
+                    ops.bwd_fused(Gs[l][t], above, stride, dh_state[l], dc_state[l], x_in,
                                   Hs[l][t], packed[l], dc_next[l], dh_next[l], slabs[l], mode, grads[l][0],
                                   durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
                     dc_state[l], dc_next[l] = dc_next[l], dc_state[l]
@@ -615,7 +619,10 @@ class _WideSequenceFunction(torch.autograd.Function):
               list(torch.empty([t_run, B, H, W, Fh], dtype=dt, device=dev).unbind(0)) for s in range(k)]
         Cs = [[c0[..., Fh * s:Fh * s + Fh].to(torch.float32).contiguous()] +
               list(torch.empty([t_run, B, H, W, Fh], dtype=torch.float32, device=dev).unbind(0)) for s in range(k)]
-        Gs = [torch.empty([t_run, B, H, W, Fh, 4], dtype=dt, device=dev) if keep else None for _ in range(k)]
+        # kept for backward: the backward factors where the fused backward step exists for the groups' shape
+        layout = ops.SAVE_FACTORS if ops.bwd_fused_supported(groups[0][1], B, H, W) else ops.SAVE_GATES
+        Gs = [torch.empty([t_run] + ops.saved_shape(B, H, W, Fh, layout), dtype=dt, device=dev) if keep else None
+              for _ in range(k)]
         # every step that runs writes its whole output slice (zeros for finished samples): only steps past the
         # longest sequence need the fill
         outs = [torch.empty([B, T, H, W, Fh], dtype=dt, device=dev) for _ in range(k)]
@@ -631,12 +638,12 @@ class _WideSequenceFunction(torch.autograd.Function):
             for s in range(k):
                 ops.cell_fwd(xw[t], Hs[0][t], Cs[s][t], groups[s][1], durations_dev, t, out=outs[s][:, t],
                              out_batch_stride=T * H * W * Fh, save_gates=False, h_out=Hs[s][t + 1], c_out=Cs[s][t + 1],
-                             gates=Gs[s][t] if keep else None)
+                             gates=Gs[s][t] if keep else None, save_layout=layout)
                 if s > 0 and live is not None:
                     # a finished sample's state passes through; the kernel copied its RECURRENT input (group 0's h)
                     Hs[s][t + 1].copy_(torch.where(live, Hs[s][t + 1], Hs[s][t]))
         ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C = cell, durations_dev, t_run, C
-        ctx.saved = (xw, Hs, Cs, Gs, groups)
+        ctx.saved = (xw, Hs, Cs, Gs, groups, layout)
         ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
         ctx.set_materialize_grads(False)
         out = torch.cat(outs, dim=-1)
@@ -645,7 +652,7 @@ class _WideSequenceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_c, d_h):
         cell, durations_dev, t_run, C = ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C
-        xw, Hs, Cs, Gs, groups = ctx.saved
+        xw, Hs, Cs, Gs, groups, layout = ctx.saved
         Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
         k = F // Fh
         _, B, H, W, cs = xw.shape
@@ -655,7 +662,7 @@ class _WideSequenceFunction(torch.autograd.Function):
                                 torch.zeros([B, H, W, Fh], dtype=d, device=dev))
         # one launch per (step, group) where the fused backward step exists for the groups' shape (its carried
         # cell-state gradient is in the compute type and ping-pongs between two buffers), else three
-        fused = t_run > 0 and ops.bwd_fused_supported(groups[0][1], B, H, W)
+        fused = t_run > 0 and layout == ops.SAVE_FACTORS
         dc_state = [part(d_c, s, dt if fused else torch.float32) for s in range(k)]
         dh_state = [part(d_h, s, dt) for s in range(k)]
         if fused:
@@ -681,7 +688,7 @@ class _WideSequenceFunction(torch.autograd.Function):
                 if fused:
                     # the recurrent input of every group is group 0's h: group 0's gradient of it becomes the carried
                     # one (a finished sample keeps its carried value), the other groups' are added to it below
-                    ops.bwd_fused(Gs[s][t], Cs[s][t], Cs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
+                    ops.bwd_fused(Gs[s][t], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
                                   dc_state[s], xw[t], Hs[0][t], groups[s][1], dc_next[s], dh_next0 if s == 0 else dh_extra,
                                   slabs[s], mode, None, dx=dxw, dx_channels=cs, dx_accumulate=s > 0,
                                   durations=durations_dev, t=t)

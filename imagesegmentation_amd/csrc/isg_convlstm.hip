@@ -713,17 +713,20 @@ bool pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int poo
 int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd, const float* bias,
                   int B, int H, int W, int Cs, int F, int dtype, const int32_t* durations, int t,
                   const int32_t* hist_points, int hist, long long hist_batch_stride, const float* hist_table,
-                  void* h_out, float* c_out, void* out, long long out_batch_stride, void* gates, void* pool_out,
-                  long long pool_batch_stride, void* stream) {
+                  void* h_out, float* c_out, void* out, long long out_batch_stride, void* gates, int save_layout,
+                  void* pool_out, long long pool_batch_stride, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
     ISG_REQUIRE(x && h_prev && c_prev && packed_fwd && bias && h_out && c_out, ISG_EINVAL,
                 "isg_convlstm_cell_fwd: null pointer");
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_cell_fwd: bad shape");
     ISG_REQUIRE(hist >= 0 && (hist == 0 || (hist_points && hist_table)), ISG_EINVAL,
                 "isg_convlstm_cell_fwd: history points and table are needed when hist > 0");
+    ISG_REQUIRE(save_layout == ISG_SAVE_GATES || (save_layout == ISG_SAVE_FACTORS && (dtype == ISG_BF16 || !gates)),
+                ISG_EINVAL, "isg_convlstm_cell_fwd: save_layout %d (the backward factors exist in bf16 only)", save_layout);
     int rc = check_channels("isg_convlstm_cell_fwd", Cs, dtype);
     if (rc != ISG_OK) return rc;
     ConvParams p = {};
+    p.save_layout = save_layout;
     p.in0 = x, p.in1 = h_prev, p.c0 = Cs, p.c1 = F_;
     p.B = B, p.H = H, p.W = W;
     p.wimg = packed_fwd;
@@ -751,9 +754,11 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const fl
                                      const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                                      const int32_t* durations, int t, const int32_t* hist_points, int hist,
                                      long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
-                                     void* out, long long out_batch_stride, void* gates, void* stream) {
+                                     void* out, long long out_batch_stride, void* gates, int save_layout,
+                                     void* stream) {
     return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
-                         hist_batch_stride, hist_table, h_out, c_out, out, out_batch_stride, gates, nullptr, 0, stream);
+                         hist_batch_stride, hist_table, h_out, c_out, out, out_batch_stride, gates, save_layout, nullptr,
+                         0, stream);
 }
 
 extern "C" int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist) {
@@ -765,15 +770,16 @@ extern "C" int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, c
                                             int F, int dtype, const int32_t* durations, int t,
                                             const int32_t* hist_points, int hist, long long hist_batch_stride,
                                             const float* hist_table, void* h_out, float* c_out, void* gates,
-                                            int pool, void* pool_out, long long pool_batch_stride, void* stream) {
+                                            int save_layout, int pool, void* pool_out, long long pool_batch_stride,
+                                            void* stream) {
     ISG_REQUIRE(pool_out, ISG_EINVAL, "isg_convlstm_cell_fwd_pooled: null pooled output");
     ISG_REQUIRE(pooled_fwd_supported(Cs, F, dtype, B, H, W, pool, hist), ISG_EINVAL,
                 "isg_convlstm_cell_fwd_pooled: needs bf16, Cs 16 or 32, pool 8, H %% 8 == 0 and W %% 32 == 0 "
                 "(got Cs=%d dtype=%d pool=%d %dx%d): ask isg_convlstm_pooled_fwd_supported first",
                 Cs, dtype, pool, H, W);
     return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
-                         hist_batch_stride, hist_table, h_out, c_out, nullptr, 0, gates, pool_out, pool_batch_stride,
-                         stream);
+                         hist_batch_stride, hist_table, h_out, c_out, nullptr, 0, gates, save_layout, pool_out,
+                         pool_batch_stride, stream);
 }
 
 extern "C" int isg_convlstm_pointwise_bwd(const void* gates, const float* c_prev, const float* c_cur,

@@ -3,9 +3,12 @@
 // The three-kernel backward (pointwise -> dY in HBM -> data gradient and weight gradient each reading dY back)
 // moves dY three times: 384 of its ~1,000 bytes per pixel.  Here the pre-activation gradient dY exists only in
 // LDS.  Per 8 x 32 (or 4 x 32) pixel tile a 512-thread workgroup runs
-//   - the gate backward: dY for the tile AND its one-pixel halo from the saved gate activations, cell states and
-//     the incoming gradients (the halo pixels' values are recomputed by the neighbouring tiles, bit for bit the
-//     same) into a padded pixel-major halo image in LDS; dc_prev of the tile's own pixels goes to global memory;
+//   - the gate backward: dY for the tile AND its one-pixel halo from the backward factors the forward step saved
+//     (six products of gate activations and cell states per channel: the gate backward is linear in the incoming
+//     gradients, so it needs neither a transcendental nor the cell states here) and the incoming gradients (the
+//     halo pixels' values are recomputed by the neighbouring tiles, bit for bit the same) into a padded
+//     pixel-major halo image in LDS; dc_prev of the tile's own pixels goes to global memory; every thread keeps
+//     the sum of its own pixels' dY (the bias gradient) in registers over all tiles;
 //   - a short store phase that puts the [x | h_prev] halo tile beside it (64-byte regions of 32 channels);
 //   - phase B: the weight gradient (each wave a group of taps x one 32-column half of dY, both operands through
 //     transposing LDS reads; the accumulators stay in registers over all tiles and leave as one slab per
@@ -16,8 +19,8 @@
 // waves of every SIMD, and the operands of tile n + 2 are requested into each staging register as the gate
 // backward frees it.  The 48-row kernel (two row tiles, a 54 - 72 KB weight image) has LDS for one dY image on
 // 8-row tiles only: there every wave runs the three parts in order, with the next tile's operands in flight.
-// What bounds it: the vector ALU (about 1,300 instructions per wave and tile, two thirds of them unpacking,
-// addressing and converting around the gate arithmetic) with ~650 - 900 bytes per pixel in flight behind it.
+// What bounds it: the vector ALU (unpacking, addressing and converting around the gate arithmetic) with
+// ~600 - 800 bytes per pixel in flight behind it.
 #include <utility>
 
 #include "isg_convlstm_shared.h"
@@ -47,9 +50,7 @@ __device__ __forceinline__ unsigned long long bwd_stamp() {
 #endif
 
 struct BwdParams {
-    const void* gates;      // [B,H,W,F,4] post-activation (tanh j, sig i, sig f, sig o)
-    const float* c_prev;    // [B,H,W,F]
-    const float* c_cur;     // [B,H,W,F]
+    const void* gates;      // backward factors [B,H,W,F/4,3,8] bf16 (A, B, C, D, E, f of lstm_backward_factors)
     const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
     long long dh_above_bstride;
     int pool_shift;         // > 0: dh_above lives on the grid pooled by 2^s x 2^s windows (average pool)
@@ -108,10 +109,17 @@ struct FB {
     static_assert(TR * MT == 8 || (TR == 8 && MT == 2), "data-gradient units (tile row x row tile) per wave: 1 or 2");
     static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0, "input channels must fit the row tiles");
     static_assert(DYH_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(NDY * DYH_BYTES >= 16 * kBwdThreads * 4, "the closing bias reduction borrows the dY images");
 };
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// two floats -> one dword of two bf16 (round to nearest even): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 
 // ACC: dx is added to what the array holds (the static features' gradient over the steps of a sequence).
 template <int C0, int MT, int TR, bool PIPE, bool ACC>
@@ -163,8 +171,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const int n_iter = (tiles_per + wg_per - 1) / wg_per;
 
     // ---- where this thread's items of every pass sit in the halo tile (fixed for the whole kernel) ----
-    // gate-backward item = (halo pixel, 4 channels 4 q .. 4 q + 3): 32 bytes of gates, 16 of each cell state, 8 of each
-    // incoming gradient.  (Two channels per item was measured: the per-item bookkeeping then weighs as much as the
+    // gate-backward item = (halo pixel, 4 channels 4 q .. 4 q + 3): 48 bytes of factors, 8 of each incoming gradient.  (Two channels per item was measured: the per-item bookkeeping then weighs as much as the
     // gate arithmetic.)  512 % 4 == 0 keeps q per thread.
     const int q = tid & 3;
     int pinfo[K::NPW];      // hy | hx << 8 | exists << 31
@@ -191,8 +198,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     static_assert(K::IN_BYTES < (1 << 18), "LDS offsets are packed into 18 bits");
 
     // ---- staged operands of one tile ----
-    uint4 sg[K::NPW][2];             // gates: 4 channels x 4 gates
-    uint4 scp[K::NPW], scc[K::NPW];  // c_prev, c_cur: 4 floats
+    uint4 sf[K::NPW][3];             // the item's three chunks of backward factors
     uint2 sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 4 bf16
     uint4 sx[K::NXP];
     unsigned pw_inside = 0u, x_inside = 0u;
@@ -243,10 +249,10 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const unsigned pix = (unsigned)(cy * p.W + cx);
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
-        sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
-        sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
-        scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
-        scc[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_cur) + (size_t)(pixel * 64u + q * 16u));
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            sf[j][m] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) +
+                                                       (size_t)(pixel * (unsigned)kFactorBytesPerPixel + q * 48u + m * 16u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
                                                  (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
@@ -280,7 +286,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     for (int i = 0; i < K::NSLOT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) wacc[i][r] = 0.0f;
-    float bsum = 0.0f;
+    float bacc[16];  // bias gradient: this thread's dY columns 16 q .. 16 q + 15, summed over its own pixels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bacc[i] = 0.0f;
     // this lane's fixed read positions in the dY interior image and, per slot, in the [x | h_prev] halo image
     const char* wg_dy;
     const char* wg_in[K::NSLOT];
@@ -341,44 +349,45 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     const bool inside = (inside_bits >> j) & 1u;
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
                     const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
-                    float out[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+                    unsigned ow[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // dY of 4 channels x 4 gates, bf16 pairs
                     float dcp[4] = {bf_lo(sdc[j].x), bf_hi(sdc[j].x), bf_lo(sdc[j].y), bf_hi(sdc[j].y)};
 #ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
                     if (false) {
 #else
                     if (inside) {
 #endif
-                        const unsigned gw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
-                                                sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
-                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
-                                              __uint_as_float(scp[j].w)};
-                        const float ccv[4] = {__uint_as_float(scc[j].x), __uint_as_float(scc[j].y), __uint_as_float(scc[j].z),
-                                              __uint_as_float(scc[j].w)};
+                        // word factor_word(k, ch >> 1) holds factor k (A, B, C, D, E, f) of channels ch & ~1 (low
+                        // half) and ch | 1 (high half)
+                        const unsigned fw[12] = {sf[j][0].x, sf[j][0].y, sf[j][0].z, sf[j][0].w, sf[j][1].x, sf[j][1].y,
+                                                 sf[j][1].z, sf[j][1].w, sf[j][2].x, sf[j][2].y, sf[j][2].z, sf[j][2].w};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
                         const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
+                        float out[16];
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
-                            const float g = bf_lo(gw[2 * ch]), ig = bf_hi(gw[2 * ch]);
-                            const float fg = bf_lo(gw[2 * ch + 1]), og = bf_hi(gw[2 * ch + 1]);
+                            float fk[6];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k)
+                                fk[k] = (ch & 1) ? bf_hi(fw[factor_word(k, ch >> 1)]) : bf_lo(fw[factor_word(k, ch >> 1)]);
                             const float dh = da[ch] * inv_pool + ds[ch];
-                            const float tc = act_tanh<true>(ccv[ch]);
-                            const float d_o = dh * tc;
-                            const float dct = dcp[ch] + dh * og * (1.0f - tc * tc);
-                            out[4 * ch] = dct * ig * (1.0f - g * g);
-                            out[4 * ch + 1] = dct * g * ig * (1.0f - ig);
-                            out[4 * ch + 2] = dct * cpv[ch] * fg * (1.0f - fg);
-                            out[4 * ch + 3] = d_o * og * (1.0f - og);
-                            dcp[ch] = dct * fg;
+                            const float dct = dcp[ch] + dh * fk[4];
+                            out[4 * ch] = dct * fk[0];
+                            out[4 * ch + 1] = dct * fk[1];
+                            out[4 * ch + 2] = dct * fk[2];
+                            out[4 * ch + 3] = dh * fk[3];
+                            dcp[ch] = dct * fk[5];
                         }
+                        // the bias gradient: dY summed over the pixels this tile owns (halo pixels belong to a neighbour)
+                        const float ownf = own ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) bacc[i] = fmaf(ownf, out[i], bacc[i]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ow[i] = pack_bf2(out[2 * i], out[2 * i + 1]);
                     }
-                    const bf16x8 o0 = {(T)out[0], (T)out[1], (T)out[2], (T)out[3], (T)out[4], (T)out[5], (T)out[6], (T)out[7]};
-                    const bf16x8 o1 = {(T)out[8],  (T)out[9],  (T)out[10], (T)out[11],
-                                       (T)out[12], (T)out[13], (T)out[14], (T)out[15]};
+                    const uint4 o0 = make_uint4(ow[0], ow[1], ow[2], ow[3]), o1 = make_uint4(ow[4], ow[5], ow[6], ow[7]);
                     char* dh_dst = dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
-                    *reinterpret_cast<bf16x8*>(dh_dst) = o0;
-                    *reinterpret_cast<bf16x8*>(dh_dst + 16) = o1;
+                    *reinterpret_cast<uint4*>(dh_dst) = o0;
+                    *reinterpret_cast<uint4*>(dh_dst + 16) = o1;
                     if (own && inside) {
                         const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
                         *reinterpret_cast<bf16x4*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 8u)) =
@@ -390,8 +399,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                                 const int tx = m_hp[2 * i] - gx + 1, ty = m_hp[2 * i + 1] - gy + 1;
                                 if (i < p.hist && m_hp[2 * i] >= 0 && (unsigned)tx < 3u && (unsigned)ty < 3u) {
                                     T* hd = static_cast<T*>(p.hist_dy) + ((((size_t)c.b * p.hist + i) * 9 + ty * 3 + tx) * NG) + q * 16;
-                                    *reinterpret_cast<bf16x8*>(hd) = o0;
-                                    *reinterpret_cast<bf16x8*>(hd + 8) = o1;
+                                    *reinterpret_cast<uint4*>(hd) = o0;
+                                    *reinterpret_cast<uint4*>(hd + 8) = o1;
                                 }
                             }
                         }
@@ -506,10 +515,6 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     if (ks + 1 < 2 * TR) fetch(ks + 1, cs ^ 1);
                 } else {
                     fetch(ks, 0);
-                }
-                if (wg_grp == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) bsum += (float)bq[cs][jj];
                 }
 #pragma unroll
                 for (int i = 0; i < K::NSLOT; ++i)
@@ -748,12 +753,18 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             }
         }
     }
-    if (wg_grp == 0) {
-        const float v = bsum + __shfl_xor(bsum, 32);
-        if (half == 0) {
-            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * wg_n + lane;
-            *dst = p.slab_accumulate ? *dst + v : v;
-        }
+    // the bias sums of the 128 threads that share q, through LDS (every wave is past its last tile), in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds_dyh);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[i * kBwdThreads + tid] = bacc[i];
+    __syncthreads();
+    if (tid < NG) {
+        const int qq = tid >> 4, i = tid & 15;
+        float v = 0.0f;
+        for (int k = 0; k < kBwdThreads / 4; ++k) v += red[i * kBwdThreads + 4 * k + qq];
+        float* dst = p.bias_slab + (size_t)blockIdx.x * NG + tid;
+        *dst = p.slab_accumulate ? *dst + v : v;
     }
 }
 
@@ -825,7 +836,7 @@ int bwd_num_cus() {
 
 bool bwd_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
     return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32 || Cs == 48) && hist >= 0 && hist <= 2 && B >= 1 && H >= 1 && W >= 1 &&
-           (long long)B * H * W * 128 < (1LL << 32);
+           (long long)B * H * W * kFactorBytesPerPixel < (1LL << 32);
 }
 
 }  // namespace
@@ -845,8 +856,7 @@ extern "C" long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist) {
     return hist_dy_bytes(B, hist) + (long long)kHistGroups * 9 * hist * NG * 4;
 }
 
-extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
-                                      long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* dh_above, long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
                                       const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
                                       int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
                                       int t, const int32_t* hist_points, int hist, long long hist_batch_stride,
@@ -856,7 +866,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
-    ISG_REQUIRE(gates && c_prev && c_cur && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
+    ISG_REQUIRE(gates && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
                     dh_state && dc_state, ISG_EINVAL, "isg_convlstm_bwd_fused: null pointer");
     ISG_REQUIRE(dc_prev != dc_state && dh_prev != dh_state, ISG_EINVAL,
                 "isg_convlstm_bwd_fused: dc_prev / dh_prev must not alias dc_state / dh_state (neighbouring tiles read "
@@ -879,7 +889,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = (Cs + F_ + 31) / 32;
     BwdParams p = {};
-    p.gates = gates, p.c_prev = c_prev, p.c_cur = c_cur;
+    p.gates = gates;
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
     p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
     p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;

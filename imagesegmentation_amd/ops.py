@@ -185,11 +185,23 @@ def pooled_fwd_supported(packed, B, H, W, pool):
                                                              int(H), int(W), int(pool), packed.hist))
 
 
+SAVE_GATES, SAVE_FACTORS = 0, 1  # what a forward step keeps for the backward pass (ISG_SAVE_* of include/isg.h)
+
+
+def saved_shape(B, H, W, F, layout):
+    """Shape of the buffer a forward step saves for backward: the gate activations [B,H,W,F,4] (read by
+    ``pointwise_bwd`` together with the cell states) or the backward factors [B,H,W,F/4,3,8] (bf16; all that
+    ``bwd_fused`` reads of the forward pass; layout in include/isg.h)."""
+    return [B, H, W, F, 4] if layout == SAVE_GATES else [B, H, W, F // 4, 3, 8]
+
+
 @_timed("cell_fwd")
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
-             h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1):
+             h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1,
+             save_layout=SAVE_GATES):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
     hist_points: int32 [B,hist,2] when the packed weights carry history channels.
+    ``gates`` (or ``save_gates``): the buffer kept for backward, in ``save_layout`` (see ``saved_shape``).
     ``pool_out`` ([B, H/pool, W/pool, F] view with batch stride ``pool_batch_stride``; only where
     ``pooled_fwd_supported``) receives the window means of the emitted output instead of ``out``.
     Returns (h, c, gates)."""
@@ -201,14 +213,16 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     h = torch.empty([B, H, W, F], dtype=x.dtype, device=x.device) if h_out is None else h_out
     c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
     if gates is None and save_gates:
-        gates = torch.empty([B, H, W, F, 4], dtype=x.dtype, device=x.device)
+        gates = torch.empty(saved_shape(B, H, W, F, save_layout), dtype=x.dtype, device=x.device)
+    assert gates is None or (gates.is_contiguous() and gates.numel() == B * H * W * F * (4 if save_layout == SAVE_GATES else 6))
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     if pool_out is not None:
         assert out is None and pool_out.dtype == x.dtype
         rc = _lib.lib().isg_convlstm_cell_fwd_pooled(
             _lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd), _lib.ptr(packed.bias), B, H, W, Cs,
             F, dtype_code(x.dtype), _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,
-            _lib.ptr(packed.hist_table), _lib.ptr(h), _lib.ptr(c), _lib.ptr(gates), int(pool), pool_out.data_ptr(),
+            _lib.ptr(packed.hist_table), _lib.ptr(h), _lib.ptr(c), _lib.ptr(gates), int(save_layout), int(pool),
+            pool_out.data_ptr(),
             int(pool_batch_stride), _lib.current_stream())
         _lib.check(rc, "isg_convlstm_cell_fwd_pooled")
         return h, c, gates
@@ -217,7 +231,7 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
                                           _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,
                                           _lib.ptr(packed.hist_table), _lib.ptr(h), _lib.ptr(c),
                                           out.data_ptr() if out is not None else None, int(out_batch_stride),
-                                          _lib.ptr(gates), _lib.current_stream())
+                                          _lib.ptr(gates), int(save_layout), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_cell_fwd")
     return h, c, gates
 
@@ -319,14 +333,16 @@ _hist_scratch = {}
 
 
 @_timed("bwd_fused")
-def bwd_fused(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
+def bwd_fused(factors, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
               dh_prev, workspace, mode, dw_x, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0,
               hist_points=None, pool=1):
-    """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward, data gradient (dx
-    optional, dh_prev) and weight gradient (deferred partial sums in ``workspace``; the history taps' rows of
-    ``dw_x`` directly).  dc_state / dh_state (either may be None) are read, dc_prev / dh_prev written: different
-    buffers."""
-    B, H, W, F, _ = gates.shape
+    """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward from the ``factors``
+    the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), data gradient (dx optional, dh_prev) and
+    weight gradient (deferred partial sums in ``workspace``; the history taps' rows of ``dw_x`` directly).
+    dc_state / dh_state are read, dc_prev / dh_prev written: different buffers."""
+    B, H, W, F = h_prev.shape
+    gates = factors
+    assert factors.is_contiguous() and factors.numel() == B * H * W * F * 6 and factors.dtype == torch.bfloat16
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     scratch = None
     if packed.hist:
@@ -336,7 +352,7 @@ def bwd_fused(gates, c_prev, c_cur, dh_above, dh_above_batch_stride, dh_state, d
             n = _lib.lib().isg_convlstm_bwd_fused_hist_bytes(B, packed.hist)
             scratch = _hist_scratch[key] = torch.empty([n // 2], dtype=torch.bfloat16, device=gates.device)
     rc = _lib.lib().isg_convlstm_bwd_fused(
-        _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(c_cur), dh_above.data_ptr() if dh_above is not None else None,
+        _lib.ptr(gates), dh_above.data_ptr() if dh_above is not None else None,
         int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), _lib.ptr(x), _lib.ptr(h_prev),
         _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype), _lib.ptr(durations), int(t),
         pts, packed.hist, pts_stride, _lib.ptr(scratch), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx),

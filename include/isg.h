@@ -146,14 +146,24 @@ int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs,
 
 /* Forward step.  h_out/c_out: new state [B][H][W][F].  out (optional): the emitted output, written
  * at out + b*out_batch_stride + (y*W + x)*F so that it can land in a [B][T][H][W][F] tensor.
- * gates (optional): [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), kept for the
- * backward pass.  hist_points: int32 (x, y) pairs of this step's frames, sample b at
- * hist_points + b*hist_batch_stride, x < 0 = empty frame. */
+ * gates (optional): what the backward pass keeps of this step, in the layout `save_layout` names:
+ *   ISG_SAVE_GATES    [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), for
+ *                     isg_convlstm_pointwise_bwd (which also reads c_prev and c_out);
+ *   ISG_SAVE_FACTORS  bf16 only: per channel the six products the gate backward is linear in -
+ *                     A = i(1 - j^2), B = j i(1 - i), C = c_prev f(1 - f), D = tanh(c) o(1 - o),
+ *                     E = o(1 - tanh(c)^2), f - with dct = dc + dh E, dy = (dct A, dct B, dct C, dh D) and
+ *                     dc_prev = dct f, for isg_convlstm_bwd_fused (which then reads neither gates nor cell
+ *                     states: 192 instead of 256 bytes per pixel, and no transcendental in the backward pass).
+ *                     Layout [B][H][W][F/4][3][8]: channels 4q..4q+3 as three 16-byte chunks,
+ *                     A0 A1 B0 B1 C0 C1 D0 D1 | E0 E1 f0 f1 E2 E3 f2 f3 | A2 A3 B2 B3 C2 C3 D2 D3.
+ * hist_points: int32 (x, y) pairs of this step's frames, sample b at hist_points + b*hist_batch_stride,
+ * x < 0 = empty frame. */
+enum { ISG_SAVE_GATES = 0, ISG_SAVE_FACTORS = 1 };
 int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
                           const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                           const int32_t* durations, int t, const int32_t* hist_points, int hist,
                           long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out, void* out,
-                          long long out_batch_stride, void* gates, void* stream);
+                          long long out_batch_stride, void* gates, int save_layout, void* stream);
 
 /* The same step for a caller that only wants the emitted output AVERAGED over pool x pool windows (the head on
  * a coarser grid, see isg_avgpool_fwd): pool_out `dtype` [H/pool][W/pool][F] per sample, samples
@@ -166,7 +176,8 @@ int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const float*
                                  const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                                  const int32_t* durations, int t, const int32_t* hist_points, int hist,
                                  long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
-                                 void* gates, int pool, void* pool_out, long long pool_batch_stride, void* stream);
+                                 void* gates, int save_layout, int pool, void* pool_out, long long pool_batch_stride,
+                                 void* stream);
 
 /* Backward, step 1 (pointwise): from dL/dh (= dh_above as emitted output + dh_state as carried
  * state, either may be NULL) and dL/dc (dc_state, may be NULL) to the pre-activation gradient
@@ -210,10 +221,11 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
                               int accumulate, float* dw_x, float* dw_h, float* dbias, void* stream);
 
 /* Backward, all three steps in ONE launch (bf16): the pre-activation gradient dy is computed per tile, halo
- * included, from the saved gates / cell states and the incoming gradients, lives only in on-chip memory, and
+ * included, from the backward factors the forward step saved (`factors`: the ISG_SAVE_FACTORS layout of
+ * isg_convlstm_cell_fwd) and the incoming gradients, lives only in on-chip memory, and
  * feeds the data gradient and the weight gradient there - it is never written to or read from device memory
  * (384 fewer bytes per pixel than isg_convlstm_pointwise_bwd + _dgrad + _wgrad).  Same results as those three
- * calls up to the order of float additions.  Replaces the gradient of reference convLSTM.py:36-43 that
+ * calls up to the bf16 rounding of the factors and the order of float additions.  Replaces the gradient of reference convLSTM.py:36-43 that
  * tf.gradients derives (reference polyrnn/Model.py:108).
  *   Only where isg_convlstm_bwd_fused_supported(...) returns 1: bf16, F = 16, Cs = 16 or 32, hist <= 2.
  *   dc_state / dc_prev are bf16 and must be different buffers, as must dh_state / dh_prev (a tile recomputes its
@@ -227,10 +239,10 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   power of two.  Other arguments: as the three calls it replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
-int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const float* c_cur, const void* dh_above,
-                           long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
-                           const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad, int B,
-                           int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations, int t,
+int isg_convlstm_bwd_fused(const void* factors, const void* dh_above, long long dh_above_batch_stride,
+                           int dh_above_pool, const void* dh_state, const void* dc_state, const void* x,
+                           const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs, int F,
+                           int dtype, const int32_t* durations, int t,
                            const int32_t* hist_points, int hist, long long hist_batch_stride, void* hist_scratch,
                            void* dc_prev, void* dh_prev, void* dx, int dx_channels, int dx_channel_stride,
                            int dx_accumulate, void* workspace, int mode, float* dw_x, void* stream);
