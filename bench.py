@@ -120,8 +120,8 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
         c = torch.randn([B, P, P, F], device=dev)
         h2, c2 = torch.empty_like(h), torch.empty_like(c)
-        # what the forward step keeps for backward: the backward factors (6 per channel) where the fused backward
-        # step exists, else the gate activations (4 per channel) for the three-kernel backward
+        # what the forward step keeps for backward: the backward factors where the fused backward step exists, else
+        # the gate activations for the three-kernel backward (four values per channel either way)
         fused = ops.bwd_fused_supported(packed, B, P, P)
         layout = ops.SAVE_FACTORS if fused else ops.SAVE_GATES
         gates = torch.zeros(ops.saved_shape(B, P, P, F, layout), dtype=dt, device=dev)
@@ -139,17 +139,17 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         px = B * P * P
         # algorithmic HBM bytes per pixel: every operand read once, every result written once
         x_b, h_b, c_b, g_b = (cs if hist else c_real) * esz, F * esz, F * 4, 4 * F * esz
-        s_b = 6 * F * esz if fused else g_b  # bytes per pixel of the saved buffer
         kernels = [
             ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts,
                                               save_layout=layout), flops,
-             px * (x_b + h_b + c_b + h_b + c_b + s_b)),
+             px * (x_b + h_b + c_b + h_b + c_b + g_b)),
         ]
         top = l == len(model.rnn.cells) - 1
         pool = P // model.head_size if top else 1
         if fused:
-            # one launch: the saved factors and the three incoming gradients in (the top layer's comes from
-            # the pooled head grid), [x | h_prev] in, dc_prev / dh_prev / dx out (layer 0 adds to its running dx)
+            # one launch: the saved factors, c_prev, the step's h and the three incoming gradients in (the top
+            # layer's comes from the pooled head grid), [x | h_prev] in, dc_prev / dh_prev / dx out (layer 0 adds to
+            # its running dx)
             above = torch.randn([B, P // pool, P // pool, F], device=dev).to(dt)
             dcn, dhn = torch.empty_like(dc), torch.empty_like(dh)
             ws = ops.wgrad_workspace(cs, F, dev, cached=False)
@@ -157,11 +157,11 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
             dx_f = torch.zeros([B, P, P, dx_ch], dtype=dt, device=dev)
             acc_dx = l == 0
             dx_b = dx_ch * esz * (2 if acc_dx else 1)
-            kernels.append(("bwd_fused", lambda: ops.bwd_fused(gates, above, (P // pool) ** 2 * F, dh, dc, x, h, packed,
+            kernels.append(("bwd_fused", lambda: ops.bwd_fused(gates, c, h2, above, (P // pool) ** 2 * F, dh, dc, x, h, packed,
                                                                 dcn, dhn, ws, ops.WGRAD_DEFER, dwx, dx=dx_f,
                                                                 dx_channels=dx_ch, dx_accumulate=acc_dx, hist_points=pts,
                                                                 pool=pool),
-                            2.0 * flops, px * (s_b + h_b / (pool * pool) + 2 * h_b + x_b + h_b + 2 * h_b + dx_b)))
+                            2.0 * flops, px * (g_b + c_b + h_b + h_b / (pool * pool) + 2 * h_b + x_b + h_b + 2 * h_b + dx_b)))
         else:
             kernels += [
                 ("pointwise_bwd", lambda: ops.pointwise_bwd(gates, c, c2, dh, P * P * F, dh, dc, dy=dy, dc_prev=dcp),

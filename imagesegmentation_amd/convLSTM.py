@@ -318,8 +318,8 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
         Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
         Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=torch.float32, device=dev).unbind(0)))
-    # What a layer keeps for backward: the backward factors where the fused backward step exists for its shape
-    # (all that kernel reads of the forward pass), else the gate activations for the three-kernel backward.
+    # What a layer keeps for backward (next to its states): the backward factors where the fused backward step
+    # exists for its shape, else the gate activations for the three-kernel backward.
     layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W) else ops.SAVE_GATES for l in range(L)]
     Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, layouts[l]), dtype=dt, device=dev) for l in range(L)] \
         if save else None
@@ -539,7 +539,7 @@ class _SequenceFunction(torch.autograd.Function):
                     raise NotImplementedError("static feature channels must be a multiple of 4")
                 pts = seq.points(t) if l == 0 else None
                 if fused[l]:
-                    ops.bwd_fused(Gs[l][t], above, stride, dh_state[l], dc_state[l], x_in,
+                    ops.bwd_fused(Gs[l][t], Cs[l][t], Hs[l][t + 1], above, stride, dh_state[l], dc_state[l], x_in,
                                   Hs[l][t], packed[l], dc_next[l], dh_next[l], slabs[l], mode, grads[l][0],
                                   durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
                     dc_state[l], dc_next[l] = dc_next[l], dc_state[l]
@@ -688,7 +688,7 @@ class _WideSequenceFunction(torch.autograd.Function):
                 if fused:
                     # the recurrent input of every group is group 0's h: group 0's gradient of it becomes the carried
                     # one (a finished sample keeps its carried value), the other groups' are added to it below
-                    ops.bwd_fused(Gs[s][t], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
+                    ops.bwd_fused(Gs[s][t], Cs[s][t], Hs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
                                   dc_state[s], xw[t], Hs[0][t], groups[s][1], dc_next[s], dh_next0 if s == 0 else dh_extra,
                                   slabs[s], mode, None, dx=dxw, dx_channels=cs, dx_accumulate=s > 0,
                                   durations=durations_dev, t=t)

@@ -4,8 +4,8 @@
 // moves dY three times: 384 of its ~1,000 bytes per pixel.  Here the pre-activation gradient dY exists only in
 // LDS.  Per 8 x 32 (or 4 x 32) pixel tile a 512-thread workgroup runs
 //   - the gate backward: dY for the tile AND its one-pixel halo from the backward factors the forward step saved
-//     (six products of gate activations and cell states per channel: the gate backward is linear in the incoming
-//     gradients, so it needs neither a transcendental nor the cell states here) and the incoming gradients (the
+//     ((A, B, f, o) per channel, see lstm_backward_factors: with c_prev and this step's h they give the whole gate
+//     backward without a hyperbolic tangent and without the new cell state) and the incoming gradients (the
 //     halo pixels' values are recomputed by the neighbouring tiles, bit for bit the same) into a padded
 //     pixel-major halo image in LDS; dc_prev of the tile's own pixels goes to global memory; every thread keeps
 //     the sum of its own pixels' dY (the bias gradient) in registers over all tiles;
@@ -50,7 +50,9 @@ __device__ __forceinline__ unsigned long long bwd_stamp() {
 #endif
 
 struct BwdParams {
-    const void* gates;      // backward factors [B,H,W,F/4,3,8] bf16 (A, B, C, D, E, f of lstm_backward_factors)
+    const void* gates;      // backward factors [B,H,W,F/2,4,2] bf16 (A, B, f, o of lstm_backward_factors)
+    const float* c_prev;    // [B,H,W,F]
+    const void* h_cur;      // [B,H,W,F]: this step's new h
     const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
     long long dh_above_bstride;
     int pool_shift;         // > 0: dh_above lives on the grid pooled by 2^s x 2^s windows (average pool)
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const int n_iter = (tiles_per + wg_per - 1) / wg_per;
 
     // ---- where this thread's items of every pass sit in the halo tile (fixed for the whole kernel) ----
-    // gate-backward item = (halo pixel, 4 channels 4 q .. 4 q + 3): 48 bytes of factors, 8 of each incoming gradient.  (Two channels per item was measured: the per-item bookkeeping then weighs as much as the
+    // gate-backward item = (halo pixel, 4 channels 4 q .. 4 q + 3): 32 bytes of factors, 16 of c_prev, 8 of h and of
+    // each incoming gradient.  (Two channels per item was measured: the per-item bookkeeping then weighs as much as the
     // gate arithmetic.)  512 % 4 == 0 keeps q per thread.
     const int q = tid & 3;
     int pinfo[K::NPW];      // hy | hx << 8 | exists << 31
@@ -198,7 +201,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     static_assert(K::IN_BYTES < (1 << 18), "LDS offsets are packed into 18 bits");
 
     // ---- staged operands of one tile ----
-    uint4 sf[K::NPW][3];             // the item's three chunks of backward factors
+    uint4 sg[K::NPW][2];             // factors of the item's two channel pairs: A A B B f f o o
+    uint4 scp[K::NPW];               // c_prev: 4 floats
+    uint2 shc[K::NPW];               // this step's h: 4 bf16
     uint2 sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 4 bf16
     uint4 sx[K::NXP];
     unsigned pw_inside = 0u, x_inside = 0u;
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const unsigned pix = (unsigned)(cy * p.W + cx);
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-            sf[j][m] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) +
-                                                       (size_t)(pixel * (unsigned)kFactorBytesPerPixel + q * 48u + m * 16u));
+        sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
+        sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
+        scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
+        shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * 32u + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
                                                  (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
@@ -356,26 +361,31 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #else
                     if (inside) {
 #endif
-                        // word factor_word(k, ch >> 1) holds factor k (A, B, C, D, E, f) of channels ch & ~1 (low
-                        // half) and ch | 1 (high half)
-                        const unsigned fw[12] = {sf[j][0].x, sf[j][0].y, sf[j][0].z, sf[j][0].w, sf[j][1].x, sf[j][1].y,
-                                                 sf[j][1].z, sf[j][1].w, sf[j][2].x, sf[j][2].y, sf[j][2].z, sf[j][2].w};
+                        // word 4 (ch >> 1) + k holds value k (A, B, f, o) of channels ch & ~1 (low half) and ch | 1 (high)
+                        const unsigned fw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
+                                                sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
+                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
+                                              __uint_as_float(scp[j].w)};
+                        const float hv[4] = {bf_lo(shc[j].x), bf_hi(shc[j].x), bf_lo(shc[j].y), bf_hi(shc[j].y)};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
                         const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
                         float out[16];
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
-                            float fk[6];
+                            float fk[4];
 #pragma unroll
-                            for (int k = 0; k < 6; ++k)
-                                fk[k] = (ch & 1) ? bf_hi(fw[factor_word(k, ch >> 1)]) : bf_lo(fw[factor_word(k, ch >> 1)]);
+                            for (int k = 0; k < 4; ++k)
+                                fk[k] = (ch & 1) ? bf_hi(fw[4 * (ch >> 1) + k]) : bf_lo(fw[4 * (ch >> 1) + k]);
+                            const float fg = fk[2], og = fk[3], h = hv[ch];
+                            // o (1 - tanh(c)^2) with tanh(c) = h / o  (o = 0 only where h = 0 too: the guard keeps 0 * inf away)
+                            const float e = og - h * (h * __builtin_amdgcn_rcpf(fmaxf(og, 1e-30f)));
                             const float dh = da[ch] * inv_pool + ds[ch];
-                            const float dct = dcp[ch] + dh * fk[4];
+                            const float dct = dcp[ch] + dh * e;
                             out[4 * ch] = dct * fk[0];
                             out[4 * ch + 1] = dct * fk[1];
-                            out[4 * ch + 2] = dct * fk[2];
-                            out[4 * ch + 3] = dh * fk[3];
-                            dcp[ch] = dct * fk[5];
+                            out[4 * ch + 2] = dct * (cpv[ch] * (fg - fg * fg));
+                            out[4 * ch + 3] = dh * (h - h * og);
+                            dcp[ch] = dct * fg;
                         }
                         // the bias gradient: dY summed over the pixels this tile owns (halo pixels belong to a neighbour)
                         const float ownf = own ? 1.0f : 0.0f;
@@ -836,7 +846,7 @@ int bwd_num_cus() {
 
 bool bwd_supported(int Cs, int F, int dtype, int B, int H, int W, int hist) {
     return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32 || Cs == 48) && hist >= 0 && hist <= 2 && B >= 1 && H >= 1 && W >= 1 &&
-           (long long)B * H * W * kFactorBytesPerPixel < (1LL << 32);
+           (long long)B * H * W * 128 < (1LL << 32);
 }
 
 }  // namespace
@@ -856,7 +866,8 @@ extern "C" long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist) {
     return hist_dy_bytes(B, hist) + (long long)kHistGroups * 9 * hist * NG * 4;
 }
 
-extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* dh_above, long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const void* h_cur, const void* dh_above,
+                                      long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
                                       const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
                                       int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
                                       int t, const int32_t* hist_points, int hist, long long hist_batch_stride,
@@ -866,7 +877,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* dh_above, l
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
-    ISG_REQUIRE(gates && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
+    ISG_REQUIRE(gates && c_prev && h_cur && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
                     dh_state && dc_state, ISG_EINVAL, "isg_convlstm_bwd_fused: null pointer");
     ISG_REQUIRE(dc_prev != dc_state && dh_prev != dh_state, ISG_EINVAL,
                 "isg_convlstm_bwd_fused: dc_prev / dh_prev must not alias dc_state / dh_state (neighbouring tiles read "
@@ -889,7 +900,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* dh_above, l
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = (Cs + F_ + 31) / 32;
     BwdParams p = {};
-    p.gates = gates;
+    p.gates = gates, p.c_prev = c_prev, p.h_cur = h_cur;
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
     p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
     p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;

@@ -336,15 +336,10 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                                      __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
                                      __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
                 const bool factors = p.save_layout == ISG_SAVE_FACTORS;
-                T* gd = !p.gates ? nullptr
-                        : factors ? static_cast<T*>(p.gates) + pixel * (F_ * 6) + 2 * half * 24
-                                  : static_cast<T*>(p.gates) + pixel * NG + 32 * half;
+                T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
                 float hn[8], cn[8], gprev[4];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    // backward factors of the row tile's four channels: one 48-byte item of three 16-byte chunks,
-                    // (A, B, C, D) of the first channel pair | (E, f) of both pairs | (A, B, C, D) of the second
-                    float fprev[6], ef[8];
+                for (int t = 0; t < MT; ++t)
 #pragma unroll
                     for (int a4 = 0; a4 < 4; ++a4) {
                         const int cl = 4 * t + a4;
@@ -364,32 +359,23 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                         const float g = act_tanh<true>(z[0]), ig = act_sigmoid<true>(z[1]);
                         const float fg = act_sigmoid<true>(z[2]), og = act_sigmoid<true>(z[3]);
                         const float c = fg * cp[cl] + ig * g;
-                        const float tc = act_tanh<true>(c);
                         cn[cl] = c;
-                        hn[cl] = og * tc;
-                        if (factors) {
-                            float f6[6];
-                            lstm_backward_factors(g, ig, fg, og, cp[cl], tc, hn[cl], f6);
-                            if (cl & 1) {
-                                const float abcd[8] = {fprev[0], f6[0], fprev[1], f6[1], fprev[2], f6[2], fprev[3], f6[3]};
-                                if (gd) store8(gd + 24 * t + 8 * (a4 & 2), abcd);
-                                ef[2 * (a4 & 2)] = fprev[4], ef[2 * (a4 & 2) + 1] = f6[4];
-                                ef[2 * (a4 & 2) + 2] = fprev[5], ef[2 * (a4 & 2) + 3] = f6[5];
-                            } else {
-#pragma unroll
-                                for (int m = 0; m < 6; ++m) fprev[m] = f6[m];
-                            }
-                        } else if (cl & 1) {
+                        hn[cl] = og * act_tanh<true>(c);
+                        // kept for backward, 16 bytes per channel pair: the gate activations (j i f o | j i f o), or
+                        // the backward factors (A A B B f f o o)
+                        float s0 = g, s1 = ig;
+                        if (factors) lstm_backward_factors(g, ig, s0, s1);
+                        if (cl & 1) {
                             if (gd) {
-                                const float pair[8] = {gprev[0], gprev[1], gprev[2], gprev[3], g, ig, fg, og};
-                                store8(gd + 4 * (cl - 1), pair);
+                                const float gates_pair[8] = {gprev[0], gprev[1], gprev[2], gprev[3], s0, s1, fg, og};
+                                const float factor_pair[8] = {gprev[0], s0, gprev[1], s1, gprev[2], fg, gprev[3], og};
+                                if (factors) store8(gd + 4 * (cl - 1), factor_pair);
+                                else store8(gd + 4 * (cl - 1), gates_pair);
                             }
                         } else {
-                            gprev[0] = g, gprev[1] = ig, gprev[2] = fg, gprev[3] = og;
+                            gprev[0] = s0, gprev[1] = s1, gprev[2] = fg, gprev[3] = og;
                         }
                     }
-                    if (factors && gd) store8(gd + 24 * t + 8, ef);
-                }
                 *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
                 *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
                 store8(static_cast<T*>(p.h_out) + so, hn);

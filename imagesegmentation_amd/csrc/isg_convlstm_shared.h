@@ -90,7 +90,7 @@ struct ConvParams {
     void* h_out;           // [B,H,W,F]
     void* out;             // masked output or null; sample stride out_bstride elements
     long long out_bstride;
-    void* gates;           // [B,H,W,F,4] (g,i,f,o), or the backward factors [B,H,W,F/4,6,4]; or null
+    void* gates;           // [B,H,W,F,4] (g,i,f,o), or the backward factors [B,H,W,F/2,4,2]; or null
     int save_layout;       // ISG_SAVE_GATES / ISG_SAVE_FACTORS: what `gates` receives
     // pooled output of the ping-pong kernels: means of the masked output over 8 x 8 windows,
     // [H/8][W/8][F] per sample with sample stride pool_bstride elements; null = none
@@ -165,25 +165,16 @@ __device__ __forceinline__ float act_tanh(float z) {
 
 // The gate backward of one channel is linear in the incoming gradients (dh, dc):
 //   dct = dc + dh E;   dY = (dct A, dct B, dct C, dh D) for the gates (j, i, f, o);   dc_prev = dct f
-// with six products of forward values, A = i (1 - j^2), B = j i (1 - i), C = c_prev f (1 - f),
-// D = tanh(c') o (1 - o) = h' (1 - o), E = o (1 - tanh(c')^2) and f itself (the derivative of
-// reference convLSTM.py:40-43).  The forward kernels can save these instead of the gate activations
-// (ISG_SAVE_FACTORS): fac[k] in the order A, B, C, D, E, f.
-__device__ __forceinline__ void lstm_backward_factors(float g, float ig, float fg, float og, float cp, float tc, float h,
-                                                      float (&fac)[6]) {
-    fac[0] = ig * (1.0f - g * g);
-    fac[1] = g * (ig - ig * ig);
-    fac[2] = cp * (fg - fg * fg);
-    fac[3] = h - h * og;
-    fac[4] = og * (1.0f - tc * tc);
-    fac[5] = fg;
+// with A = i (1 - j^2), B = j i (1 - i), C = c_prev f (1 - f), D = tanh(c') o (1 - o) = h' (1 - o),
+// E = o (1 - tanh(c')^2) = o - h'^2 / o (the derivative of reference convLSTM.py:40-43).  With c_prev and h' at
+// hand - the forward pass stores both anyway - everything follows from (A, B, f, o) without a hyperbolic tangent
+// and without the new cell state.  The forward kernels can save these four instead of the gate activations
+// (ISG_SAVE_FACTORS), in the same 128 bytes per pixel: per channel pair A0 A1 B0 B1 f0 f1 o0 o1 (a 32-bit word
+// holds one value of both channels; the kernels finish channels in pairs).
+__device__ __forceinline__ void lstm_backward_factors(float g, float ig, float& a, float& b) {
+    a = ig * (1.0f - g * g);
+    b = g * (ig - ig * ig);
 }
-// Saved layout, bf16: per pixel F/4 items (channels 4 q .. 4 q + 3) of three 16-byte chunks:
-//   A0 A1 B0 B1 C0 C1 D0 D1 | E0 E1 f0 f1 E2 E3 f2 f3 | A2 A3 B2 B3 C2 C3 D2 D3
-// (a 32-bit word holds one factor of a channel pair; the forward kernels finish channels in pairs).
-constexpr int kFactorBytesPerPixel = F_ * 6 * 2;
-// 32-bit word of an item that holds factor k (0-5: A, B, C, D, E, f) of channel pair pr (0, 1)
-__host__ __device__ constexpr int factor_word(int k, int pr) { return k < 4 ? (pr ? 8 + k : k) : 4 + 2 * pr + (k - 4); }
 
 // c' = sig(f) c + sig(i) tanh(j);  h' = sig(o) tanh(c')   (reference convLSTM.py:40-43)
 template <bool FAST>
@@ -230,22 +221,17 @@ __device__ __forceinline__ void lstm_finish_pixel_with_state(const ConvParams& p
     store8(static_cast<T*>(p.h_out) + so, hn);
     if (p.out) store8(static_cast<T*>(p.out) + (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
     if (p.gates && p.save_layout == ISG_SAVE_FACTORS) {
-        // this lane's 8 channels are two items of 4 channels: [6 factors][4 channels] each
-        T* fd = static_cast<T*>(p.gates) + pixel * (F_ * 6) + 2 * half * 24;
+        T* fd = static_cast<T*>(p.gates) + pixel * NG + 32 * half;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            float item[24];
+        for (int pr = 0; pr < 4; ++pr) {  // this lane's four channel pairs
+            float v[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cl = 4 * it + k;
-                float f6[6];
-                lstm_backward_factors(gs[4 * cl], gs[4 * cl + 1], gs[4 * cl + 2], gs[4 * cl + 3], cp[cl],
-                                      act_tanh<FAST>(cn[cl]), hn[cl], f6);
-#pragma unroll
-                for (int m = 0; m < 6; ++m) item[2 * factor_word(m, k >> 1) + (k & 1)] = f6[m];
+            for (int k = 0; k < 2; ++k) {
+                const int cl = 2 * pr + k;
+                lstm_backward_factors(gs[4 * cl], gs[4 * cl + 1], v[k], v[2 + k]);
+                v[4 + k] = gs[4 * cl + 2], v[6 + k] = gs[4 * cl + 3];
             }
-#pragma unroll
-            for (int m = 0; m < 3; ++m) store8(fd + 24 * it + 8 * m, item + 8 * m);
+            store8(fd + 8 * pr, v);
         }
     } else if (p.gates) {
         T* gd = static_cast<T*>(p.gates) + pixel * NG + 32 * half;

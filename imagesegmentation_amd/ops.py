@@ -190,9 +190,9 @@ SAVE_GATES, SAVE_FACTORS = 0, 1  # what a forward step keeps for the backward pa
 
 def saved_shape(B, H, W, F, layout):
     """Shape of the buffer a forward step saves for backward: the gate activations [B,H,W,F,4] (read by
-    ``pointwise_bwd`` together with the cell states) or the backward factors [B,H,W,F/4,3,8] (bf16; all that
-    ``bwd_fused`` reads of the forward pass; layout in include/isg.h)."""
-    return [B, H, W, F, 4] if layout == SAVE_GATES else [B, H, W, F // 4, 3, 8]
+    ``pointwise_bwd`` together with both cell states) or the backward factors [B,H,W,F/2,4,2] (bf16, same size;
+    ``bwd_fused`` reads them with c_prev and the step's h; layout in include/isg.h)."""
+    return [B, H, W, F, 4] if layout == SAVE_GATES else [B, H, W, F // 2, 4, 2]
 
 
 @_timed("cell_fwd")
@@ -214,7 +214,7 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
     if gates is None and save_gates:
         gates = torch.empty(saved_shape(B, H, W, F, save_layout), dtype=x.dtype, device=x.device)
-    assert gates is None or (gates.is_contiguous() and gates.numel() == B * H * W * F * (4 if save_layout == SAVE_GATES else 6))
+    assert gates is None or (gates.is_contiguous() and gates.numel() == B * H * W * F * 4)
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     if pool_out is not None:
         assert out is None and pool_out.dtype == x.dtype
@@ -333,16 +333,18 @@ _hist_scratch = {}
 
 
 @_timed("bwd_fused")
-def bwd_fused(factors, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
+def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
               dh_prev, workspace, mode, dw_x, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0,
               hist_points=None, pool=1):
     """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward from the ``factors``
-    the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), data gradient (dx optional, dh_prev) and
+    the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), the cell state before the step (``c_prev``)
+    and the step's new h (``h_cur``); data gradient (dx optional, dh_prev) and
     weight gradient (deferred partial sums in ``workspace``; the history taps' rows of ``dw_x`` directly).
     dc_state / dh_state are read, dc_prev / dh_prev written: different buffers."""
     B, H, W, F = h_prev.shape
     gates = factors
-    assert factors.is_contiguous() and factors.numel() == B * H * W * F * 6 and factors.dtype == torch.bfloat16
+    assert factors.is_contiguous() and factors.numel() == B * H * W * F * 4 and factors.dtype == torch.bfloat16
+    assert c_prev.dtype == torch.float32 and h_cur.dtype == torch.bfloat16
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     scratch = None
     if packed.hist:
@@ -352,7 +354,7 @@ def bwd_fused(factors, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h
             n = _lib.lib().isg_convlstm_bwd_fused_hist_bytes(B, packed.hist)
             scratch = _hist_scratch[key] = torch.empty([n // 2], dtype=torch.bfloat16, device=gates.device)
     rc = _lib.lib().isg_convlstm_bwd_fused(
-        _lib.ptr(gates), dh_above.data_ptr() if dh_above is not None else None,
+        _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(h_cur), dh_above.data_ptr() if dh_above is not None else None,
         int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), _lib.ptr(x), _lib.ptr(h_prev),
         _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype), _lib.ptr(durations), int(t),
         pts, packed.hist, pts_stride, _lib.ptr(scratch), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx),

@@ -149,13 +149,12 @@ int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs,
  * gates (optional): what the backward pass keeps of this step, in the layout `save_layout` names:
  *   ISG_SAVE_GATES    [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), for
  *                     isg_convlstm_pointwise_bwd (which also reads c_prev and c_out);
- *   ISG_SAVE_FACTORS  bf16 only: per channel the six products the gate backward is linear in -
- *                     A = i(1 - j^2), B = j i(1 - i), C = c_prev f(1 - f), D = tanh(c) o(1 - o),
- *                     E = o(1 - tanh(c)^2), f - with dct = dc + dh E, dy = (dct A, dct B, dct C, dh D) and
- *                     dc_prev = dct f, for isg_convlstm_bwd_fused (which then reads neither gates nor cell
- *                     states: 192 instead of 256 bytes per pixel, and no transcendental in the backward pass).
- *                     Layout [B][H][W][F/4][3][8]: channels 4q..4q+3 as three 16-byte chunks,
- *                     A0 A1 B0 B1 C0 C1 D0 D1 | E0 E1 f0 f1 E2 E3 f2 f3 | A2 A3 B2 B3 C2 C3 D2 D3.
+ *   ISG_SAVE_FACTORS  bf16 only, same size: [B][H][W][F/2][4][2], per channel pair A0 A1 B0 B1 f0 f1 o0 o1 with
+ *                     A = i(1 - j^2), B = j i(1 - i), for isg_convlstm_bwd_fused.  The gate backward is linear
+ *                     in (dh, dc): dct = dc + dh E, dy = (dct A, dct B, dct C, dh D), dc_prev = dct f, where
+ *                     C = c_prev f(1 - f), D = h(1 - o) and E = o - h^2/o (h = this step's h_out) need neither
+ *                     a hyperbolic tangent nor the new cell state: that kernel reads c_prev and h_out instead
+ *                     of c_prev and c_out (224 instead of 256 bytes per pixel).
  * hist_points: int32 (x, y) pairs of this step's frames, sample b at hist_points + b*hist_batch_stride,
  * x < 0 = empty frame. */
 enum { ISG_SAVE_GATES = 0, ISG_SAVE_FACTORS = 1 };
@@ -222,7 +221,8 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
 
 /* Backward, all three steps in ONE launch (bf16): the pre-activation gradient dy is computed per tile, halo
  * included, from the backward factors the forward step saved (`factors`: the ISG_SAVE_FACTORS layout of
- * isg_convlstm_cell_fwd) and the incoming gradients, lives only in on-chip memory, and
+ * isg_convlstm_cell_fwd), the cell state before the step (c_prev), the step's output state (h_cur = its h_out)
+ * and the incoming gradients, lives only in on-chip memory, and
  * feeds the data gradient and the weight gradient there - it is never written to or read from device memory
  * (384 fewer bytes per pixel than isg_convlstm_pointwise_bwd + _dgrad + _wgrad).  Same results as those three
  * calls up to the bf16 rounding of the factors and the order of float additions.  Replaces the gradient of reference convLSTM.py:36-43 that
@@ -239,8 +239,8 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   power of two.  Other arguments: as the three calls it replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
-int isg_convlstm_bwd_fused(const void* factors, const void* dh_above, long long dh_above_batch_stride,
-                           int dh_above_pool, const void* dh_state, const void* dc_state, const void* x,
+int isg_convlstm_bwd_fused(const void* factors, const float* c_prev, const void* h_cur, const void* dh_above,
+                           long long dh_above_batch_stride, int dh_above_pool, const void* dh_state, const void* dc_state, const void* x,
                            const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs, int F,
                            int dtype, const int32_t* durations, int t,
                            const int32_t* hist_points, int hist, long long hist_batch_stride, void* hist_scratch,

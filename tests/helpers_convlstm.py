@@ -114,16 +114,11 @@ def flat_grad_list(grads):
     return out + [grads["dense"]["w"], grads["dense"]["b"]]
 
 
-def backward_factors(gates, c_prev, c_cur):
-    """The six products per channel that the fused backward step reads (include/isg.h, ISG_SAVE_FACTORS), from
-    gate activations [.., F, 4] (tanh j, sig i, sig f, sig o) and the cell states before / after the step:
-    returns a float64 tensor [.., F/4, 3, 8] in the saved layout
-    A0 A1 B0 B1 C0 C1 D0 D1 | E0 E1 f0 f1 E2 E3 f2 f3 | A2 A3 B2 B3 C2 C3 D2 D3."""
+def backward_factors(gates):
+    """What a forward step saves for the fused backward step (include/isg.h, ISG_SAVE_FACTORS), from gate
+    activations [.., F, 4] (tanh j, sig i, sig f, sig o): float64 [.., F/2, 4, 2], per channel pair
+    A0 A1 B0 B1 f0 f1 o0 o1 with A = i (1 - j^2), B = j i (1 - i)."""
     g, i, f, o = [gates[..., k].double() for k in range(4)]
-    cp, tc = c_prev.double(), torch.tanh(c_cur.double())
-    fac = torch.stack([i * (1 - g * g), g * i * (1 - i), cp * f * (1 - f), tc * o * (1 - o), o * (1 - tc * tc), f], dim=-1)
+    fac = torch.stack([i * (1 - g * g), g * i * (1 - i), f, o], dim=-1)   # [.., F, 4]
     lead = fac.shape[:-2]
-    fac = fac.reshape(*lead, fac.shape[-2] // 4, 2, 2, 6)            # [.., item, pair, channel of pair, factor]
-    abcd = fac[..., :4].transpose(-1, -2).reshape(*lead, -1, 2, 8)   # per pair: A0 A1 B0 B1 C0 C1 D0 D1
-    ef = fac[..., 4:].transpose(-1, -2).reshape(*lead, -1, 8)        # E0 E1 f0 f1 E2 E3 f2 f3
-    return torch.stack([abcd[..., 0, :], ef, abcd[..., 1, :]], dim=-2)
+    return fac.reshape(*lead, fac.shape[-2] // 2, 2, 4).transpose(-1, -2).contiguous()

@@ -76,7 +76,7 @@ def test_new_entry_points_reject_bad_arguments_on_the_host():
     assert lib.isg_convlstm_bwd_fused_supported(16, 16, 1, 2, 8, 8, 3) == 0   # more than two history frames
 
     def fused(cs=16, dh_state=one, dh_prev=two, dc_state=one, dc_prev=two, mode=2, pool=1, above=one):
-        return lib.isg_convlstm_bwd_fused(one, above, 0, pool, dh_state, dc_state, one, one, one, 2, 8, 8, cs, cs, 16,
+        return lib.isg_convlstm_bwd_fused(one, one, one, above, 0, pool, dh_state, dc_state, one, one, one, 2, 8, 8, cs, cs, 16,
                                           1, None, 0, None, 0, 0, None, dc_prev, dh_prev, None, 0, 0, 0, one, mode, None,
                                           None)
 

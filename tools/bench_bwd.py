@@ -39,7 +39,7 @@ def main():
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
         c0, c1 = torch.randn([B, P, P, F], device=dev), torch.randn([B, P, P, F], device=dev)
         gates = torch.rand([B, P, P, F, 4], device=dev).to(dt)
-        factors = torch.rand([B, P, P, F // 4, 3, 8], device=dev).to(dt)
+        factors = torch.rand([B, P, P, F // 2, 4, 2], device=dev).to(dt)
         dh_above = torch.randn([B, P, P, F], device=dev).to(dt)
         dh, dc = torch.randn([B, P, P, F], device=dev).to(dt), torch.randn([B, P, P, F], device=dev).to(dt)
         dh2, dc2 = torch.empty_like(dh), torch.empty_like(dc)
@@ -48,7 +48,7 @@ def main():
         ws = ops.wgrad_workspace(cs, F, dev, cached=False)
         dwx, dwh, db = torch.zeros_like(w_x), torch.zeros_like(w_h), torch.zeros([64], device=dev)
         acc = cs == 32
-        fused = lambda: ops.bwd_fused(factors, dh_above, P * P * F, dh, dc, x, h, packed, dc2, dh2, ws,
+        fused = lambda: ops.bwd_fused(factors, c0, h, dh_above, P * P * F, dh, dc, x, h, packed, dc2, dh2, ws,
                                       ops.WGRAD_DEFER, dwx, dx=dx, dx_channels=dx.shape[-1], dx_accumulate=acc,
                                       hist_points=pts)
 

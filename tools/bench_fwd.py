@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: the forward cell step alone at the benchmark shape (B=64, 224x224, bf16), both layer shapes, with the
+saved buffer in either layout.  ISG_LIBRARY selects a variant build of the library.
+usage: python tools/bench_fwd.py [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from imagesegmentation_amd import ops  # noqa: E402
+from bench_bwd import timed  # noqa: E402
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dev = torch.device("cuda:0")
+    B, P, F, dt = 64, 224, 16, torch.bfloat16
+    out = []
+    for cs, c_real, hist in ((32, 33, 1), (16, 16, 0)):
+        w_x = torch.randn([3, 3, c_real, 64], device=dev) * 0.05
+        w_h = torch.randn([3, 3, F, 64], device=dev) * 0.05
+        packed = ops.PackedWeights(w_x, w_h, torch.zeros([64], device=dev), cs, dt, hist=hist)
+        pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
+        x = torch.randn([B, P, P, cs], device=dev).to(dt)
+        h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
+        c = torch.randn([B, P, P, F], device=dev)
+        h2, c2 = torch.empty_like(h), torch.empty_like(c)
+        saved = torch.empty([B, P, P, F, 4], dtype=dt, device=dev)
+        for name, layout in (("gates", ops.SAVE_GATES), ("factors", ops.SAVE_FACTORS)):
+            fn = lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=saved, hist_points=pts, save_layout=layout)
+            out.append("Cs=%d %s %.4f ms" % (cs, name, timed(fn, reps)))
+        fn = lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, save_gates=False, hist_points=pts)
+        out.append("Cs=%d nothing saved %.4f ms" % (cs, timed(fn, reps)))
+    print(os.environ.get("ISG_LIBRARY", "default"), " | ".join(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -39,14 +39,14 @@ def main():
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
         c0, c1 = torch.randn([B, P, P, F], device=dev), torch.randn([B, P, P, F], device=dev)
         gates = torch.rand([B, P, P, F, 4], device=dev).to(dt)
-        factors = torch.rand([B, P, P, F // 4, 3, 8], device=dev).to(dt)
+        factors = torch.rand([B, P, P, F // 2, 4, 2], device=dev).to(dt)
         above = torch.randn([B, P, P, F], device=dev).to(dt)
         dh, dc = torch.randn([B, P, P, F], device=dev).to(dt), torch.randn([B, P, P, F], device=dev).to(dt)
         dh2, dc2 = torch.empty_like(dh), torch.empty_like(dc)
         dx = torch.zeros([B, P, P, cs if cs == 32 else F], dtype=dt, device=dev)
         ws = ops.wgrad_workspace(cs, F, dev, cached=False)
         dwx = torch.zeros_like(w_x)
-        fn = lambda: ops.bwd_fused(factors, above, P * P * F, dh, dc, x, h, packed, dc2, dh2, ws, ops.WGRAD_DEFER,
+        fn = lambda: ops.bwd_fused(factors, c0, h, above, P * P * F, dh, dc, x, h, packed, dc2, dh2, ws, ops.WGRAD_DEFER,
                                    dwx, dx=dx, dx_channels=dx.shape[-1], dx_accumulate=cs == 32, hist_points=pts)
         buf = torch.zeros([256 * 2 * 8], dtype=torch.int64, device=dev)
         lib.isg_debug_set_bwd_stamp_buffer(buf.data_ptr())
