@@ -48,6 +48,9 @@ SIGNATURES = {
     "isg_conv32_wgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_conv16_packed_elems": (_ll, [_int]),
     "isg_conv16": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
+    "isg_conv32_masked_workspace_bytes": (_ll, []),
+    "isg_conv32_masked": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "isg_conv16_masked": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_conv16_wgrad_workspace_bytes": (_ll, [_int]),
     "isg_conv16_wgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_avgpool_fwd": (_int, [_vp, _ll, _int, _int, _int, _int, _int, _vp, _vp]),

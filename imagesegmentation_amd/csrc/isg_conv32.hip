@@ -4,7 +4,9 @@
 // the 32-row MFMA tile is half zero rows: these layers move 64 bytes per pixel, the matrix pipe has room.
 //   forward / data gradient:  D[row][pixel] = sum_k A[row][k] * X[k][pixel]; the caller's weight image
 //       decides which of the two it is (data gradient = flipped taps, transposed channels);
-//       optional bias and ReLU in the epilogue.
+//       optional bias and ReLU in the epilogue - or, for a data gradient that lands on the ReLU output of the
+//       layer below, that layer's ReLU mask and its bias gradient (the masked values summed per channel),
+//       which saves the separate mask-and-sum pass over the tensor.
 //   weight gradient:          D[cin][cout] = sum_pixels X[pixel + tap][cin] * dZ[pixel][cout].
 // These layers move 150 - 200 bytes per pixel against 18 - 51 kFLOP: HBM-bound, so the kernels are
 // plain persistent tiles with the weight image resident in LDS and the next tile in flight in
@@ -68,9 +70,14 @@ struct Conv32Params {
     const float* bias; // [CH] or null
     void* y;           // [B,H,W,CH] bf16
     int B, H, W, tiles_x, tiles_y, relu;
+    const void* mask;      // MASK: [B,H,W,CH] bf16, the output keeps its value where mask > 0 and is zero elsewhere
+    float* bias_partial;   // MASK: [grid][32] sums of the kept values per channel
 };
 
-template <int KS, int CH>
+constexpr int kMaskedMaxBlocks = 1024;
+
+// MASK: no bias, no ReLU; the epilogue applies `mask` and sums what it keeps (see the top of the file).
+template <int KS, int CH, bool MASK>
 __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
     using K = CF<KS, CH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +132,12 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         }
     };
 
+    float bsum[4][4];  // MASK: this lane's kept values summed over its pixels, rows 8 g + 4 half + i
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[g][i] = 0.0f;
+
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -133,6 +146,16 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         const bool valid = tile_origin(k, b, ty0, tx0);
         stage_load(k + 1);
         if (valid) {
+            uint2 mk[2][2 * K::SPT];  // MASK: the mask values of this lane's rows, requested ahead of the k-loop
+            if constexpr (MASK) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int cy = min(ty0 + 2 * wave + pt, p.H - 1), cx = min(tx0 + px_l, p.W - 1);
+                    const char* src = static_cast<const char*>(p.mask) + (((size_t)b * p.H + cy) * p.W + cx) * (CH * 2);
+#pragma unroll
+                    for (int g = 0; g < 2 * K::SPT; ++g) mk[pt][g] = *reinterpret_cast<const uint2*>(src + (8 * g + 4 * half) * 2);
+                }
+            }
             f32x16 acc[2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt)
@@ -156,13 +179,25 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 unsigned pk[4][2];
+                const bool px_in = ty0 + 2 * wave + pt < p.H && tx0 + px_l < p.W;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v[i] = acc[pt][4 * g + i] + lds_bias[8 * g + 4 * half + i];
-                        if (p.relu) v[i] = fmaxf(v[i], 0.0f);
+                        if constexpr (MASK) {
+                            v[i] = acc[pt][4 * g + i];
+                            if (g < 2 * K::SPT) {
+                                // (a ReLU output is never negative: positive = any bit below the sign)
+                                const unsigned word = i < 2 ? mk[pt][g].x : mk[pt][g].y;
+                                const bool keep = (word & ((i & 1) ? 0x7FFF0000u : 0x00007FFFu)) != 0u;
+                                v[i] = keep ? v[i] : 0.0f;
+                                bsum[g][i] += px_in ? v[i] : 0.0f;
+                            }
+                        } else {
+                            v[i] = acc[pt][4 * g + i] + lds_bias[8 * g + 4 * half + i];
+                            if (p.relu) v[i] = fmaxf(v[i], 0.0f);
+                        }
                     }
                     pk[g][0] = pack2(v[0], v[1]), pk[g][1] = pack2(v[2], v[3]);
                 }
@@ -190,6 +225,42 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         __syncthreads();  // every wave is done reading the tile
         stage_store(k + 1);
         __syncthreads();
+    }
+    if constexpr (MASK) {
+        // per row: the 32 pixels of a half-wave, then the 8 waves through LDS (the tile buffer is free now)
+        float* red = reinterpret_cast<float*>(lds_in);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = bsum[g][i];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+                if (px_l == 0) red[(wave * 2 + half) * 16 + 4 * g + i] = s;
+            }
+        __syncthreads();
+        if (tid < MROWS) {
+            const int g = tid >> 3, hf = (tid >> 2) & 1, i = tid & 3;
+            float s = 0.0f;
+            for (int w = 0; w < kThreads / 64; ++w) s += red[(w * 2 + hf) * 16 + 4 * g + i];
+            p.bias_partial[(size_t)blockIdx.x * MROWS + tid] = s;
+        }
+    }
+}
+
+// dbias[c] = sum over workgroups of bias_partial[workgroup][c], in a fixed order
+__global__ __launch_bounds__(256) void conv32_bias_reduce_kernel(const float* __restrict__ partial, int nblocks, int CH,
+                                                                 float* __restrict__ dbias) {
+    __shared__ float red[8][MROWS];
+    const int c = threadIdx.x & (MROWS - 1), part = threadIdx.x >> 5;
+    float s = 0.0f;
+    for (int b = part; b < nblocks; b += 8) s += partial[(size_t)b * MROWS + c];
+    red[part][c] = s;
+    __syncthreads();
+    if (part == 0 && c < CH) {
+        float v = 0.0f;
+        for (int k = 0; k < 8; ++k) v += red[k][c];
+        dbias[c] = v;
     }
 }
 
@@ -379,19 +450,24 @@ __global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* _
     if (sg == 0 && idx < n) dw[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
-template <int KS, int CH>
-int launch_conv32(Conv32Params& p, hipStream_t s) {
+template <int KS, int CH, bool MASK>
+int launch_conv32(Conv32Params& p, float* dbias, hipStream_t s) {
     using K = CF<KS, CH>;
     static_assert(K::LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(K::IN_BYTES >= 2 * (kThreads / 64) * 16 * 4, "the closing bias reduction borrows the tile buffer");
     p.tiles_x = (p.W + TW - 1) / TW, p.tiles_y = (p.H + K::TH - 1) / K::TH;
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int per_cu = (160 * 1024) / K::LDS_BYTES >= 2 ? 2 : 1;
-    const int grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<KS, CH>),
+    int grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+    if (MASK && grid > kMaskedMaxBlocks) grid = kMaskedMaxBlocks;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<KS, CH, MASK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((conv32_kernel<KS, CH>), dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
-    return isg::check_launch("conv32_kernel");
+    hipLaunchKernelGGL((conv32_kernel<KS, CH, MASK>), dim3(grid), dim3(kThreads), K::LDS_BYTES, s, p);
+    int rc = isg::check_launch("conv32_kernel");
+    if (!MASK || rc != ISG_OK) return rc;
+    hipLaunchKernelGGL(conv32_bias_reduce_kernel, dim3(1), dim3(256), 0, s, p.bias_partial, grid, CH, dbias);
+    return isg::check_launch("conv32_bias_reduce_kernel");
 }
 
 template <int KS, int CH>
@@ -420,8 +496,21 @@ int conv_same(const char* who, int CH, const void* x, const void* wimg, const fl
     Conv32Params p = {};
     p.x = x, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (CH == 32) return KS == 3 ? launch_conv32<3, 32>(p, s) : launch_conv32<5, 32>(p, s);
-    return KS == 3 ? launch_conv32<3, 16>(p, s) : launch_conv32<5, 16>(p, s);
+    if (CH == 32) return KS == 3 ? launch_conv32<3, 32, false>(p, nullptr, s) : launch_conv32<5, 32, false>(p, nullptr, s);
+    return KS == 3 ? launch_conv32<3, 16, false>(p, nullptr, s) : launch_conv32<5, 16, false>(p, nullptr, s);
+}
+
+int conv_same_masked(const char* who, int CH, const void* x, const void* wimg, const void* mask, int B, int H, int W,
+                     int KS, void* y, float* dbias, void* workspace, void* stream) {
+    ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "%s: kernel size %d has no instantiation (3, 5)", who, KS);
+    ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "%s: bad shape", who);
+    ISG_REQUIRE(x && wimg && mask && y && dbias && workspace, ISG_EINVAL, "%s: null pointer", who);
+    Conv32Params p = {};
+    p.x = x, p.wimg = wimg, p.y = y, p.B = B, p.H = H, p.W = W;
+    p.mask = mask, p.bias_partial = static_cast<float*>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (CH == 32) return KS == 3 ? launch_conv32<3, 32, true>(p, dbias, s) : launch_conv32<5, 32, true>(p, dbias, s);
+    return KS == 3 ? launch_conv32<3, 16, true>(p, dbias, s) : launch_conv32<5, 16, true>(p, dbias, s);
 }
 
 int conv_same_wgrad(const char* who, int CH, const void* x, const void* dz, int B, int H, int W, int KS, void* workspace,
@@ -446,6 +535,18 @@ extern "C" long long isg_conv32_packed_elems(int KS) {
 extern "C" int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
                           void* y, void* stream) {
     return conv_same("isg_conv32", 32, x, wimg, bias, B, H, W, KS, relu, y, stream);
+}
+
+extern "C" long long isg_conv32_masked_workspace_bytes(void) { return (long long)kMaskedMaxBlocks * MROWS * (long long)sizeof(float); }
+
+extern "C" int isg_conv32_masked(const void* x, const void* wimg, const void* mask, int B, int H, int W, int KS, void* y,
+                                 float* dbias, void* workspace, void* stream) {
+    return conv_same_masked("isg_conv32_masked", 32, x, wimg, mask, B, H, W, KS, y, dbias, workspace, stream);
+}
+
+extern "C" int isg_conv16_masked(const void* x, const void* wimg, const void* mask, int B, int H, int W, int KS, void* y,
+                                 float* dbias, void* workspace, void* stream) {
+    return conv_same_masked("isg_conv16_masked", 16, x, wimg, mask, B, H, W, KS, y, dbias, workspace, stream);
 }
 
 extern "C" long long isg_conv32_wgrad_workspace_bytes(int KS) {

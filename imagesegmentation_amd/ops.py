@@ -499,6 +499,30 @@ def conv32(x, wimg, bias, ks, relu):
     return y
 
 
+_conv32_mask_ws = {}
+
+
+def conv32_masked(dz, wimg_dgrad, y_below, ks):
+    """(dz_below, dbias_below): the data gradient of a conv32 / conv16 layer masked by the ReLU of the layer below
+    (``y_below`` = that layer's output) and the masked values summed per channel (float32 [C]) - the layer below's
+    ReLU backward and bias gradient without a pass of their own (isg_conv32_masked)."""
+    B, H, W, c = dz.shape
+    assert c in (16, 32) and dz.dtype == torch.bfloat16 and dz.is_contiguous()
+    assert y_below.shape == dz.shape and y_below.dtype == dz.dtype and y_below.is_contiguous()
+    key = str(dz.device)
+    ws = _conv32_mask_ws.get(key)
+    if ws is None:
+        ws = _conv32_mask_ws[key] = torch.empty([_lib.lib().isg_conv32_masked_workspace_bytes() // 4], dtype=torch.float32,
+                                                device=dz.device)
+    out = torch.empty_like(dz)
+    dbias = torch.empty([c], dtype=torch.float32, device=dz.device)
+    fn = _lib.lib().isg_conv32_masked if c == 32 else _lib.lib().isg_conv16_masked
+    rc = fn(_lib.ptr(dz), _lib.ptr(wimg_dgrad), _lib.ptr(y_below), B, H, W, int(ks), _lib.ptr(out), _lib.ptr(dbias),
+            _lib.ptr(ws), _lib.current_stream())
+    _lib.check(rc, "isg_conv%d_masked" % c)
+    return out, dbias
+
+
 _conv32_ws = {}
 
 

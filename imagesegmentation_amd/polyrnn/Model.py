@@ -107,6 +107,51 @@ class _Conv32(torch.autograd.Function):
         return dx, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
 
 
+class _EncoderChain(torch.autograd.Function):
+    """A whole encoder of hand-written layers - the first on the isg_conv_in kernels, the others on isg_conv32 /
+    isg_conv16 - as one autograd node (reference polyrnn/History2LargeExperiment.py:15-22,
+    polyrnn/RNNConvExperiment.py:14-22).  Seen as a chain, the backward pass needs the separate ReLU-mask and
+    bias-gradient pass only for the top layer: every data gradient lands on the ReLU output of the layer below
+    and applies that layer's mask and sums its bias gradient in its own epilogue (isg_conv32_masked)."""
+
+    @staticmethod
+    def forward(ctx, x3, *params):
+        ws, bs = params[0::2], params[1::2]
+        x4 = ops.conv_in_pad_image(x3.contiguous())
+        ys = [ops.conv_in_fwd(x4, ops.conv_in_pack(ws[0]), bs[0].detach().float().contiguous(), ws[0].shape[0], relu=True)]
+        for w, b in zip(ws[1:], bs[1:]):
+            ys.append(ops.conv32(ys[-1], ops.conv32_pack(w), b.detach().float().contiguous(), w.shape[0], relu=True))
+        ctx.save_for_backward(x4, *ys, *ws)
+        ctx.n = len(ws)
+        ctx.dtypes = [p.dtype for p in params]
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        x4, ys, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        grads = [None] * (2 * n)
+        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), ys[-1])
+        for k in range(n - 1, 0, -1):
+            ks = ws[k].shape[0]
+            grads[2 * k] = ops.conv32_wgrad(ys[k - 1], dz, ks).to(ctx.dtypes[2 * k])
+            grads[2 * k + 1] = dbias.to(ctx.dtypes[2 * k + 1])
+            dz, dbias = ops.conv32_masked(dz, ops.conv32_pack(ws[k], data_gradient=True), ys[k - 1], ks)
+        grads[0] = ops.conv_in_wgrad(x4, dz, ws[0].shape[0]).to(ctx.dtypes[0])
+        grads[1] = dbias.to(ctx.dtypes[1])
+        return (None,) + tuple(grads)
+
+
+def encoder_chain_supported(x_nhwc, encoder, dtype):
+    """Whether ``_EncoderChain`` takes this encoder: an input that needs no gradient, a first layer for the
+    isg_conv_in kernels and at least one more layer, all of those for the isg_conv32 / isg_conv16 kernels."""
+    if x_nhwc.requires_grad or len(encoder) < 2 or x_nhwc.dtype != dtype or os.environ.get("ISG_NO_ENCODER_CHAIN"):
+        return False  # (the environment switch: layer-by-layer nodes, for A/B runs)
+    (w0, _), rest = encoder[0], encoder[1:]
+    return ops.conv_in_supported(w0, dtype, x_nhwc.device) and \
+        all(ops.conv32_supported(w, dtype, x_nhwc.device) and w.shape[2] == w0.shape[3] for w, _ in rest)
+
+
 def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     """tf.layers.conv2d(padding='same', activation=relu) on an NHWC tensor with an HWIO kernel
     (reference polyrnn/History2LargeExperiment.py:15-22).  Even kernels pad (k-1)//2 before and the
@@ -287,6 +332,8 @@ class Model:
 
     def encode(self, images):
         x = self._to_dev(images, self.compute_dtype).contiguous()
+        if torch.is_grad_enabled() and encoder_chain_supported(x, self.encoder, self.compute_dtype):
+            return _EncoderChain.apply(x, *[p for wb in self.encoder for p in wb])
         for w, b in self.encoder:
             x = conv2d_same_relu(x, w, b, self.compute_dtype)
         return x

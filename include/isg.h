@@ -382,6 +382,15 @@ int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H,
 long long isg_conv32_wgrad_workspace_bytes(int KS);
 int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                      void* stream);
+/* The data gradient of a layer whose input is the ReLU output of the layer below, with that layer's ReLU
+ * backward in the epilogue: y = conv(x, wimg) where mask > 0, else 0 (mask = the lower layer's output, same
+ * shape as y), and dbias float [32] = the sum of y over all pixels - the lower layer's bias gradient.  Replaces
+ * isg_conv32(relu = 0) followed by isg_relu_bwd_bias: one pass over the tensor less.  Part of the gradient
+ * tf.gradients derives for the encoder (reference polyrnn/Model.py:108).  workspace: device scratch of
+ * isg_conv32_masked_workspace_bytes() bytes. */
+long long isg_conv32_masked_workspace_bytes(void);
+int isg_conv32_masked(const void* x, const void* wimg, const void* mask, int B, int H, int W, int KS, void* y,
+                      float* dbias, void* workspace, void* stream);
 
 /* ---- the same for 16 -> 16 channels ---------------------------------------------------------------------
  * The 16-channel encoder layers of reference polyrnn/History2LargeExperiment.py:15-22 (5 x 5 and 3 x 3) and of
@@ -391,6 +400,8 @@ int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS,
 long long isg_conv16_packed_elems(int KS);
 int isg_conv16(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
                void* stream);
+int isg_conv16_masked(const void* x, const void* wimg, const void* mask, int B, int H, int W, int KS, void* y,
+                      float* dbias /* [16] */, void* workspace, void* stream);
 long long isg_conv16_wgrad_workspace_bytes(int KS);
 int isg_conv16_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                      void* stream);

@@ -325,6 +325,73 @@ def test_encoder_square_convolution_kernels_against_float64_conv(KS, C):
     assert rel_err(dw, ref_dw) < 1e-4  # float accumulation of exact bf16 products
 
 
+@pytest.mark.parametrize("C", [32, 16])
+@pytest.mark.parametrize("KS", [3, 5])
+def test_masked_data_gradient_equals_data_gradient_then_relu_backward(KS, C):
+    """isg_conv32_masked / isg_conv16_masked (data gradient with the lower layer's ReLU mask and bias gradient in
+    the epilogue) against the two passes it replaces, isg_conv32(relu = 0) then isg_relu_bwd_bias: the masked
+    gradient bit for bit (same accumulation, same rounding), the bias gradient up to the order of float additions,
+    and against its float64 value.  Ragged image size: partial tiles contribute nothing to the sums."""
+    from imagesegmentation_amd import ops
+    rs = np.random.RandomState(10 * KS + C)
+    B, H, W = 3, 37, 45
+    dev = "cuda:0"
+    bf = lambda a: torch.tensor(a, device=dev).to(torch.bfloat16)
+    tw = torch.tensor(rs.randn(KS, KS, C, C) * 0.05, dtype=torch.float32, device=dev)
+    wimg = ops.conv32_pack(tw, data_gradient=True)
+    dz = bf(rs.randn(B, H, W, C))
+    y_below = bf(np.maximum(rs.randn(B, H, W, C), 0.0))         # a ReLU output: about half of it zero
+    got, got_db = ops.conv32_masked(dz, wimg, y_below, KS)
+    lin = ops.conv32(dz, wimg, None, KS, relu=False)
+    want, want_db = ops.relu_bwd_bias(lin, y_below)
+    assert torch.equal(got, want)
+    # The fused epilogue sums the float values it masks, the separate pass the bf16-rounded tensor it reads: they
+    # differ by the accumulated rounding (about 2^-9 sqrt(n) per channel), and the fused sum is the one closer to
+    # the float64 value of the unrounded gradient.
+    assert float((got_db - want_db).abs().max()) <= 5e-3 * float(want_db.abs().max())
+    w64 = tw.to(torch.bfloat16).double().cpu().numpy()   # the weights as the kernel sees them
+    lin64, _, _ = oc.conv2d_same_backward(np.zeros([B, H, W, C]), w64, dz.double().cpu().numpy())
+    ref_db = (lin64 * (y_below.double().cpu().numpy() > 0)).sum(axis=(0, 1, 2))
+    assert np.abs(got_db.double().cpu().numpy() - ref_db).max() <= 1e-4 * np.abs(ref_db).max() + 1e-3
+    assert np.abs(got_db.double().cpu().numpy() - ref_db).max() <= np.abs(want_db.double().cpu().numpy() - ref_db).max()
+
+
+def test_encoder_chain_gradients_equal_the_layer_by_layer_backward():
+    """The encoder as one autograd node (ReLU backward of every layer but the top one inside the data-gradient
+    kernels) against the same layers as separate nodes: equal outputs, equal gradients."""
+    from imagesegmentation_amd.polyrnn import Model as M
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    dt, dev = torch.bfloat16, torch.device("cuda:0")
+    B, P = 3, 40
+    x = (torch.rand([B, P, P, 3], device=dev, generator=g) > 0.5).to(dt)
+    spec = [(3, 32, 14), (32, 32, 5), (32, 32, 3)]
+    params = []
+    for cin, cout, k in spec:
+        params.append(((torch.randn([k, k, cin, cout], device=dev, generator=g) * (1.5 / (k * k * cin) ** 0.5)).requires_grad_(True),
+                       (torch.randn([cout], device=dev, generator=g) * 0.1).requires_grad_(True)))
+    d_out = torch.randn([B, P, P, 32], device=dev, generator=g).to(dt)
+    assert M.encoder_chain_supported(x, params, dt)
+
+    def grads(chain):
+        for w, b in params:
+            w.grad = b.grad = None
+        if chain:
+            y = M._EncoderChain.apply(x, *[p for wb in params for p in wb])
+        else:
+            y = x
+            for w, b in params:
+                y = M.conv2d_same_relu(y, w, b, dt)
+        (y.float() * d_out.float()).sum().backward()
+        return y.detach().clone(), [(w.grad.clone(), b.grad.clone()) for w, b in params]
+
+    y1, g1 = grads(True)
+    y0, g0 = grads(False)
+    assert torch.equal(y1, y0)
+    for (dw1, db1), (dw0, db0) in zip(g1, g0):
+        assert float((dw1 - dw0).abs().max()) <= 1e-5 * float(dw0.abs().max()) + 1e-6   # same masked gradients in
+        assert float((db1 - db0).abs().max()) <= 5e-3 * float(db0.abs().max()) + 1e-3   # float vs bf16-rounded sums
+
+
 @pytest.mark.parametrize("name", ["History2Large", "History0", "RNNConv", "EndTokenDeep_2"])
 def test_fp32_model_against_committed_golden_outputs(name):
     """The HIP path (f32) against tests/golden/convlstm_golden.npz - the oracle's frozen logits, loss, metrics
