@@ -12,6 +12,7 @@ gate blocks j|i|f|o) and are float32; ``compute_dtype`` selects float32 (f32 MFM
 MFMA, float32 accumulation and cell state) for the activations.  ``forget_bias`` is accepted and, as
 in the reference, never used.
 """
+import os
 import collections
 import math
 
@@ -312,6 +313,10 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     # shape, kept for the life of the process and only ever read - neither a fill nor a copy per sequence.
     n_buf = T if save else 2
     Hs, Cs = [], []
+    # a layer that starts from the zero state: its first step is told so and reads no state at all
+    # (ISG_NO_ZERO_STATE=1: the shared zero tensors are read like any state, for A/B runs)
+    from_zero = [init_state[l][0] is None and init_state[l][1] is None and not os.environ.get("ISG_NO_ZERO_STATE")
+                 for l in range(L)]
     for l in range(L):
         c0, h0 = init_state[l]
         c_init = _zero_state([B, H, W, F], torch.float32, dev) if c0 is None else c0.detach().to(torch.float32).contiguous()
@@ -336,7 +341,8 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         for l in range(L):
             ops.set_layer(l)
             top = l == L - 1
-            ops.cell_fwd(x, Hs[l][cur], Cs[l][cur], packed[l], durations_dev, t,
+            first = t == 0 and from_zero[l]
+            ops.cell_fwd(x, None if first else Hs[l][cur], None if first else Cs[l][cur], packed[l], durations_dev, t,
                          out=out[:, t] if top and not fused_pool else None, out_batch_stride=T * H * W * F,
                          save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
                          save_layout=layouts[l], hist_points=seq.points(t) if l == 0 else None,
@@ -539,9 +545,13 @@ class _SequenceFunction(torch.autograd.Function):
                     raise NotImplementedError("static feature channels must be a multiple of 4")
                 pts = seq.points(t) if l == 0 else None
                 if fused[l]:
-                    ops.bwd_fused(Gs[l][t], Cs[l][t], Hs[l][t + 1], above, stride, dh_state[l], dc_state[l], x_in,
-                                  Hs[l][t], packed[l], dc_next[l], dh_next[l], slabs[l], mode, grads[l][0],
-                                  durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
+                    # the first step of a layer that started from the zero state: no state to read, and nobody
+                    # wants the gradient of that state
+                    first = t == 0 and ctx.state_dtypes[l] == (None, None) and not os.environ.get("ISG_NO_ZERO_STATE")
+                    ops.bwd_fused(Gs[l][t], None if first else Cs[l][t], Hs[l][t + 1], above, stride, dh_state[l],
+                                  dc_state[l], x_in, None if first else Hs[l][t], packed[l],
+                                  None if first else dc_next[l], None if first else dh_next[l], slabs[l], mode,
+                                  grads[l][0], durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
                     dc_state[l], dc_next[l] = dc_next[l], dc_state[l]
                     dh_state[l], dh_next[l] = dh_next[l], dh_state[l]
                     continue

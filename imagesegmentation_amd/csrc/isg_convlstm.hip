@@ -86,7 +86,7 @@ __device__ __forceinline__ void stage_tile(const void* in0, const void* in1, int
         const int hy = px / HALO_W, hx = px - hy * HALO_W;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && (ch < n0 || in1 != nullptr)) {  // (in1 null: all zero)
             const size_t pixel = ((size_t)b * H + gy) * W + gx;
             const T* src = ch < n0 ? static_cast<const T*>(in0) + pixel * c0 + ch * CH
                                    : static_cast<const T*>(in1) + pixel * c1 + (ch - n0) * CH;
@@ -716,8 +716,9 @@ int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const 
                   void* h_out, float* c_out, void* out, long long out_batch_stride, void* gates, int save_layout,
                   void* pool_out, long long pool_batch_stride, void* stream) {
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
-    ISG_REQUIRE(x && h_prev && c_prev && packed_fwd && bias && h_out && c_out, ISG_EINVAL,
-                "isg_convlstm_cell_fwd: null pointer");
+    ISG_REQUIRE(x && packed_fwd && bias && h_out && c_out, ISG_EINVAL, "isg_convlstm_cell_fwd: null pointer");
+    ISG_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), ISG_EINVAL,
+                "isg_convlstm_cell_fwd: h_prev and c_prev are both given or both NULL (the zero state)");
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_cell_fwd: bad shape");
     ISG_REQUIRE(hist >= 0 && (hist == 0 || (hist_points && hist_table)), ISG_EINVAL,
                 "isg_convlstm_cell_fwd: history points and table are needed when hist > 0");

@@ -231,6 +231,12 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         return r;
     };
     const float inv_pool = 1.0f / (float)(1 << (2 * p.pool_shift));
+    // The step out of the zero state (c_prev and h_prev null): nothing is read for either - the loads stay
+    // unconditional and re-read the first bytes of another operand - and zeros are used in their place.
+    const bool zero_state = p.c_prev == nullptr;
+    const char* cp_base = zero_state ? static_cast<const char*>(p.gates) : reinterpret_cast<const char*>(p.c_prev);
+    const char* hp_tensor = zero_state ? static_cast<const char*>(p.x) : static_cast<const char*>(p.h_prev);
+    const unsigned state_mul = zero_state ? 0u : 1u, state_mask = zero_state ? 0u : 0xFFFFFFFFu;
     const int* dur_base = p.durations != nullptr ? p.durations : reinterpret_cast<const int*>(p.gates);
     const int dur_mul = p.durations != nullptr ? 1 : 0;
     const int* hp_base = p.hist > 0 ? p.hist_points : reinterpret_cast<const int*>(p.gates);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
         sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
         sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
-        scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
+        scp[j] = *reinterpret_cast<const uint4*>(cp_base + (size_t)((pixel * 64u + q * 16u) * state_mul));
         shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * 32u + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const unsigned pixel = (unsigned)((r.b * p.H + cy) * p.W + cx);
         const bool is_h = ch >= K::NCH0;
-        const char* base = is_h ? static_cast<const char*>(p.h_prev) : static_cast<const char*>(p.x);
-        const unsigned off = is_h ? pixel * (unsigned)(F_ * 2) + (unsigned)(ch - K::NCH0) * 16u
+        const char* base = is_h ? hp_tensor : static_cast<const char*>(p.x);
+        const unsigned off = is_h ? (pixel * (unsigned)(F_ * 2) + (unsigned)(ch - K::NCH0) * 16u) * state_mul
                                   : pixel * (unsigned)(C0 * 2) + (unsigned)ch * 16u;
         sx[j] = *reinterpret_cast<const uint4*>(base + (size_t)off);
     };
@@ -364,8 +370,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         // word 4 (ch >> 1) + k holds value k (A, B, f, o) of channels ch & ~1 (low half) and ch | 1 (high)
                         const unsigned fw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
                                                 sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
-                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
-                                              __uint_as_float(scp[j].w)};
+                        const float cpv[4] = {__uint_as_float(scp[j].x & state_mask), __uint_as_float(scp[j].y & state_mask),
+                                              __uint_as_float(scp[j].z & state_mask), __uint_as_float(scp[j].w & state_mask)};
                         const float hv[4] = {bf_lo(shc[j].x), bf_hi(shc[j].x), bf_lo(shc[j].y), bf_hi(shc[j].y)};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
                         const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
@@ -400,8 +406,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     *reinterpret_cast<uint4*>(dh_dst + 16) = o1;
                     if (own && inside) {
                         const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
-                        *reinterpret_cast<bf16x4*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 8u)) =
-                            bf16x4{(T)dcp[0], (T)dcp[1], (T)dcp[2], (T)dcp[3]};
+                        if (p.dc_prev)  // (null: nobody wants the gradient of the state before this step)
+                            *reinterpret_cast<bf16x4*>(static_cast<char*>(p.dc_prev) + (size_t)(pixel * 32u + q * 8u)) =
+                                bf16x4{(T)dcp[0], (T)dcp[1], (T)dcp[2], (T)dcp[3]};
                         if (p.hist > 0) {
                             // dY at the pixels the history taps reach, kept for the tap weights' gradient
 #pragma unroll
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     int inf = xinfo[j];
                     asm volatile("" : "+v"(inf));
                     if (inf < 0) {
-                        const bool inside = (x_inside >> j) & 1u;
+                        const bool inside = ((x_inside >> j) & 1u) && !(zero_state && ((inf >> 28) & 7) >= K::NCH0);
                         *reinterpret_cast<uint4*>(lds_in + (inf & 0x3ffff)) = inside ? sx[j] : make_uint4(0u, 0u, 0u, 0u);
                     }
                 }(), ...);
@@ -450,10 +457,12 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 if (gy < p.H && gx < p.W) {
                     const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
                     const size_t so = (size_t)(pixel * 32u + qq * 4u);
-                    *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
-                        *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
-                    *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
-                        *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
+                    if (p.dc_prev) {
+                        *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
+                            *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
+                        *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
+                            *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
+                    }
                     if (p.dx && !p.dx_accumulate)
                         for (int ch = 2 * qq; ch < p.dx_channels; ch += 16)
                             *reinterpret_cast<unsigned*>(static_cast<T*>(p.dx) + (size_t)pixel * p.dx_cstride + ch) = 0u;
@@ -593,13 +602,13 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     if (cc0 < C0) {
                         if (p.dx && cc0 < p.dx_channels)
                             store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
-                    } else if (cc0 < C0 + F_) {
+                    } else if (cc0 < C0 + F_ && p.dh_prev) {
                         store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)((cc0 - C0) * 2))), v);
                     }
                 }
             }
         }
-        if constexpr (K::WCOMPACT) {
+        if constexpr (K::WCOMPACT) if (p.dh_prev != nullptr) {  // (this row tile is dh_prev alone: skipped when nobody wants it)
             // The second row tile holds 16 real rows (h_prev's channels): 16 x 16 x 32 MFMAs, two per 32-deep k-step
             // (pixels 0-15 and 16-31 of the tile row), half the matrix-pipe time of a 32-row tile that is half
             // padding.  The compact weight image is already in this instruction's A layout: lane l reads 16 bytes
@@ -877,9 +886,12 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
-    ISG_REQUIRE(gates && c_prev && h_cur && x && h_prev && packed_dgrad && dc_prev && dh_prev && workspace && dh_above &&
-                    dh_state && dc_state, ISG_EINVAL, "isg_convlstm_bwd_fused: null pointer");
-    ISG_REQUIRE(dc_prev != dc_state && dh_prev != dh_state, ISG_EINVAL,
+    ISG_REQUIRE(gates && h_cur && x && packed_dgrad && workspace && dh_above && dh_state && dc_state, ISG_EINVAL,
+                "isg_convlstm_bwd_fused: null pointer");
+    ISG_REQUIRE((c_prev == nullptr) == (h_prev == nullptr) && (dc_prev == nullptr) == (dh_prev == nullptr), ISG_EINVAL,
+                "isg_convlstm_bwd_fused: c_prev / h_prev are both given or both NULL (the step out of the zero state), "
+                "and so are dc_prev / dh_prev (NULL: not wanted)");
+    ISG_REQUIRE(dc_prev == nullptr || (dc_prev != dc_state && dh_prev != dh_state), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: dc_prev / dh_prev must not alias dc_state / dh_state (neighbouring tiles read "
                 "the incoming gradients of each other's border pixels)");
     ISG_REQUIRE(mode == ISG_WGRAD_DEFER_FIRST || mode == ISG_WGRAD_DEFER, ISG_EINVAL,

@@ -154,6 +154,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         const unsigned ldso = px * K::PSTRIDE + (K::SWZ ? chunk ^ (px & 7) : chunk) * 16;
         info[j] = ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
     }
+    const bool in1_zero = C1 > 0 && p.in1 == nullptr;  // forward step from the zero state (h_prev and c_prev NULL)
+    const char* in1_base = static_cast<const char*>(in1_zero ? p.in0 : p.in1);
+    const unsigned in1_mul = in1_zero ? 0u : 1u;
     auto stage_load = [&](const TileRef& r) {
         if (!r.valid) return;
         st_inside = 0u;
@@ -180,9 +183,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             if (j < K::NL0)
                 st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in0) +
                                                         (size_t)(pixel * (unsigned)(C0 * 2) + chunk_bytes));
-            else
-                st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in1) +
-                                                        (size_t)(pixel * (unsigned)(C1 * 2) + chunk_bytes));
+            else  // (the zero state: every lane re-reads the first bytes of in0 and stage_store writes zeros - an
+                  // unconditional load, like all the others here)
+                st[j] = *reinterpret_cast<const uint4*>(in1_base + (size_t)((pixel * (unsigned)(C1 * 2) + chunk_bytes) * in1_mul));
         }
     };
     auto stage_store = [&](TileRef& r) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         for (int j = 0; j < K::NLOAD; ++j) {
             unsigned inf = info[j];
             if constexpr (K::SWZ) asm volatile("" : "+v"(inf));  // as in stage_load
-            const bool in = (st_inside >> j) & 1u;
+            const bool in = ((st_inside >> j) & 1u) && !(j >= K::NL0 && in1_zero);
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
             if (inf & 0x80000000u) *reinterpret_cast<uint4*>(lds_in + (inf & 0xFFFFu)) = v;
         }
@@ -278,7 +281,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             const int gy = min(r.ty0 + NPT * wave + pt, p.H - 1), gx = min(r.tx0 + px_l, p.W - 1);
             const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
             if constexpr (MODE == 0) {
-                const uint4* src = reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half);
+                // (the zero state: every lane re-reads the bias instead, and the epilogue takes zeros)
+                const uint4* src = p.c_prev ? reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half)
+                                            : reinterpret_cast<const uint4*>(p.bias);
                 pre[2 * pt] = src[0];
                 pre[2 * pt + 1] = src[1];
             } else {
@@ -331,10 +336,11 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 // state; gate activations leave as 16-byte stores every second channel
                 const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
                 const size_t so = pixel * F_ + 8 * half;
-                const float cp[8] = {__uint_as_float(pre[2 * pt].x),     __uint_as_float(pre[2 * pt].y),
-                                     __uint_as_float(pre[2 * pt].z),     __uint_as_float(pre[2 * pt].w),
-                                     __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
-                                     __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
+                const unsigned cmask = p.c_prev ? 0xFFFFFFFFu : 0u;  // (no previous state: zeros)
+                const float cp[8] = {__uint_as_float(pre[2 * pt].x & cmask),     __uint_as_float(pre[2 * pt].y & cmask),
+                                     __uint_as_float(pre[2 * pt].z & cmask),     __uint_as_float(pre[2 * pt].w & cmask),
+                                     __uint_as_float(pre[2 * pt + 1].x & cmask), __uint_as_float(pre[2 * pt + 1].y & cmask),
+                                     __uint_as_float(pre[2 * pt + 1].z & cmask), __uint_as_float(pre[2 * pt + 1].w & cmask)};
                 const bool factors = p.save_layout == ISG_SAVE_FACTORS;
                 T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
                 float hn[8], cn[8], gprev[4];

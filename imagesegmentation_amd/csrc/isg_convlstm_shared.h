@@ -245,8 +245,11 @@ template <typename T, bool FAST>
 __device__ __forceinline__ void lstm_finish_pixel(const ConvParams& p, int b, int gy, int gx, int half, float (&z)[32],
                                                   const float* table) {
     const size_t so = (((size_t)b * p.H + gy) * p.W + gx) * F_ + 8 * half;
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.c_prev + so);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.c_prev + so + 4);
+    f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0;  // (c_prev null: the zero state)
+    if (p.c_prev) {
+        c0 = *reinterpret_cast<const f32x4*>(p.c_prev + so);
+        c1 = *reinterpret_cast<const f32x4*>(p.c_prev + so + 4);
+    }
     const float cp[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
     lstm_finish_pixel_with_state<T, FAST>(p, b, gy, gx, half, z, cp, table);
 }
@@ -262,9 +265,13 @@ __device__ __forceinline__ void lstm_copy_through_tile(const ConvParams& p, int 
         if (gy < p.H && gx < p.W) {
             const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
             const size_t o = pixel * F_ + q4 * 4;
-            *reinterpret_cast<f32x4*>(p.c_out + o) = *reinterpret_cast<const f32x4*>(p.c_prev + o);
-            float hv[4];
-            load4(static_cast<const T*>(p.in1) + o, hv);
+            float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 cv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (p.c_prev) {  // (null: the zero state passes through as zeros)
+                cv = *reinterpret_cast<const f32x4*>(p.c_prev + o);
+                load4(static_cast<const T*>(p.in1) + o, hv);
+            }
+            *reinterpret_cast<f32x4*>(p.c_out + o) = cv;
             store4(static_cast<T*>(p.h_out) + o, hv);
             if (p.out) {
                 const float zero[4] = {0.f, 0.f, 0.f, 0.f};

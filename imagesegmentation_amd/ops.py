@@ -200,6 +200,7 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
              h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1,
              save_layout=SAVE_GATES):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
+    h_prev = c_prev = None: the zero state.
     hist_points: int32 [B,hist,2] when the packed weights carry history channels.
     ``gates`` (or ``save_gates``): the buffer kept for backward, in ``save_layout`` (see ``saved_shape``).
     ``pool_out`` ([B, H/pool, W/pool, F] view with batch stride ``pool_batch_stride``; only where
@@ -208,8 +209,9 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     _need_cuda(x, "x")
     B, H, W, Cs = x.shape
     F = packed.f
-    assert Cs == packed.cs and x.dtype == packed.dtype and h_prev.dtype == packed.dtype
-    assert c_prev.dtype == torch.float32
+    assert Cs == packed.cs and x.dtype == packed.dtype
+    assert (h_prev is None) == (c_prev is None)  # both None: the zero state, nothing is read for it
+    assert h_prev is None or (h_prev.dtype == packed.dtype and c_prev.dtype == torch.float32)
     h = torch.empty([B, H, W, F], dtype=x.dtype, device=x.device) if h_out is None else h_out
     c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
     if gates is None and save_gates:
@@ -340,11 +342,12 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
     the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), the cell state before the step (``c_prev``)
     and the step's new h (``h_cur``); data gradient (dx optional, dh_prev) and
     weight gradient (deferred partial sums in ``workspace``; the history taps' rows of ``dw_x`` directly).
-    dc_state / dh_state are read, dc_prev / dh_prev written: different buffers."""
-    B, H, W, F = h_prev.shape
+    dc_state / dh_state are read, dc_prev / dh_prev written: different buffers.  c_prev = h_prev = None: the step
+    out of the zero state; dc_prev = dh_prev = None: the gradient of the state before the step is not wanted."""
+    B, H, W, F = h_cur.shape
     gates = factors
     assert factors.is_contiguous() and factors.numel() == B * H * W * F * 4 and factors.dtype == torch.bfloat16
-    assert c_prev.dtype == torch.float32 and h_cur.dtype == torch.bfloat16
+    assert (c_prev is None or c_prev.dtype == torch.float32) and h_cur.dtype == torch.bfloat16
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     scratch = None
     if packed.hist:

@@ -144,7 +144,8 @@ int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs,
                               void* packed_fwd, void* packed_dgrad /* either may be NULL */, float* hist_table,
                               void* stream);
 
-/* Forward step.  h_out/c_out: new state [B][H][W][F].  out (optional): the emitted output, written
+/* Forward step.  h_prev and c_prev may both be NULL: the zero state (nothing is read for it; the first step of a
+ * sequence that starts from dynamic_rnn's default state).  h_out/c_out: new state [B][H][W][F].  out (optional): the emitted output, written
  * at out + b*out_batch_stride + (y*W + x)*F so that it can land in a [B][T][H][W][F] tensor.
  * gates (optional): what the backward pass keeps of this step, in the layout `save_layout` names:
  *   ISG_SAVE_GATES    [B][H][W][F][4] post-activation (tanh j, sig i, sig f, sig o), for
@@ -236,7 +237,10 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   to the hist channels of dw_x (assigned / added by the same mode) through hist_scratch, device scratch of
  *   isg_convlstm_bwd_fused_hist_bytes(B, hist) bytes.
  *   dh_above, dh_state and dc_state must all be given (zeros where there is no gradient); dh_above_pool is a
- *   power of two.  Other arguments: as the three calls it replaces. */
+ *   power of two.  c_prev and h_prev may both be NULL: the step out of the zero state (nothing is read for
+ *   them; the rows of dw_h and of the h part get zero contributions).  dc_prev and dh_prev may both be NULL:
+ *   the gradient of the state before this step is not wanted (nothing is written, and where the kernel has a
+ *   row tile of its own for dh_prev it is skipped).  Other arguments: as the three calls it replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
 int isg_convlstm_bwd_fused(const void* factors, const float* c_prev, const void* h_cur, const void* dh_above,

@@ -676,3 +676,42 @@ def test_fused_backward_step_against_float64_gate_backward():
     want_db = dy.sum(dim=(0, 1, 2)).transpose(0, 1).reshape(-1)                          # gate blocks j|i|f|o
     assert float((db.double() - want_db).abs().max()) <= 1e-2 * float(want_db.abs().max()) + 1e-2
     assert torch.equal(dh2[1], dh[1]) and torch.equal(dc2[1], dc[1]) and float(dx[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_first_step_out_of_the_zero_state_reads_no_state(dtype, monkeypatch):
+    """A sequence that starts from dynamic_rnn's default state tells the first step of every layer so (h_prev and
+    c_prev NULL; in the reverse sweep also dc_prev / dh_prev NULL): outputs, final states and every gradient are
+    the ones of the same sequence with the zero tensors read like any state (ISG_NO_ZERO_STATE=1) - bit for bit.
+    A sample with duration 0 passes the zero state through."""
+    from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
+    rs = np.random.RandomState(41)
+    T, B, H, W, Cf, hist, L = 3, 4, 19, 37, 32, 1, 2
+    _, multi = _stack(rs, Cf + hist, L, dtype, (H, W))
+    feat = torch.tensor(rs.randn(B, H, W, Cf), dtype=dtype, device=dev())
+    pts = torch.tensor(rs.randint(0, 19, [B, T, hist, 2]).astype(np.int32), device=dev())
+    durations = np.array([T, 0, 2, 1], np.int32)
+    d_out = torch.tensor(rs.randn(B, T, H, W, 16), dtype=torch.float32, device=dev())
+
+    def run(shortcut):
+        if shortcut:
+            monkeypatch.delenv("ISG_NO_ZERO_STATE", raising=False)
+        else:
+            monkeypatch.setenv("ISG_NO_ZERO_STATE", "1")
+        for cell in multi.cells:
+            for prm in (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias):
+                prm.grad = None
+        leaf = feat.clone().requires_grad_(True)
+        out, final = dynamic_rnn(multi, SequenceInput(static=leaf, hist_points=pts), sequence_length=durations,
+                                 time_major=False)
+        loss = (out.float() * d_out).sum() + sum((f.c.sum() + f.h.float().sum()) for f in final)
+        loss.backward()
+        got = [out.detach().clone(), leaf.grad.clone()] + [t.detach().clone() for f in final for t in (f.c, f.h)]
+        for cell in multi.cells:
+            got += [cell.input_to_state_kernel.grad.clone(), cell.hidden_to_state_kernel.grad.clone(), cell.bias.grad.clone()]
+        return got
+
+    want, got = run(False), run(True)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert float(got[0][1].abs().max()) == 0.0 and float(got[2][1].abs().max()) == 0.0   # the empty sample: zeros
