@@ -494,13 +494,17 @@ class _SequenceFunction(torch.autograd.Function):
         d_out = d_out.to(dt).contiguous() if d_out is not None else \
             torch.zeros([B, T, H // pool, W // pool, F], dtype=dt, device=dev)
         dc_state, dh_state = [], []
+        fused = [layouts[l] == ops.SAVE_FACTORS for l in range(L)]
+        # a layer whose final state has no gradient tells the first step of its sweep so (nothing is read for it)
+        # where the fused backward step runs; elsewhere it starts from zeros
+        no_carry = [fused[l] and t_run > 0 and d_final[2 * l] is None and d_final[2 * l + 1] is None and
+                    not os.environ.get("ISG_NO_ZERO_STATE") for l in range(L)]
         for l in range(L):
             dc, dh = d_final[2 * l], d_final[2 * l + 1]
+            make = torch.empty if no_carry[l] else torch.zeros
             # the cell-state gradient is carried between steps in the activation dtype, like dL/dh
-            dc_state.append(dc.to(dt).clone().contiguous() if dc is not None else
-                            torch.zeros([B, H, W, F], dtype=dt, device=dev))
-            dh_state.append(dh.to(dt).clone().contiguous() if dh is not None else
-                            torch.zeros([B, H, W, F], dtype=dt, device=dev))
+            dc_state.append(dc.to(dt).clone().contiguous() if dc is not None else make([B, H, W, F], dtype=dt, device=dev))
+            dh_state.append(dh.to(dt).clone().contiguous() if dh is not None else make([B, H, W, F], dtype=dt, device=dev))
         grads = []
         for cell in cells:
             grads.append((torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32),
@@ -522,7 +526,6 @@ class _SequenceFunction(torch.autograd.Function):
         slabs = [ops.wgrad_workspace(packed[l].cs, F, dev, cached=False) for l in range(L)]
         # One launch per (step, layer) where the fused backward kernel exists (bf16): it reads the incoming state
         # gradients of neighbouring tiles' border pixels, so they alternate between two buffers per layer.
-        fused = [layouts[l] == ops.SAVE_FACTORS for l in range(L)]
         dc_next = [torch.empty_like(dc_state[l]) if fused[l] else None for l in range(L)]
         dh_next = [torch.empty_like(dh_state[l]) if fused[l] else None for l in range(L)]
         for t in reversed(range(t_run)):
@@ -548,8 +551,10 @@ class _SequenceFunction(torch.autograd.Function):
                     # the first step of a layer that started from the zero state: no state to read, and nobody
                     # wants the gradient of that state
                     first = t == 0 and ctx.state_dtypes[l] == (None, None) and not os.environ.get("ISG_NO_ZERO_STATE")
-                    ops.bwd_fused(Gs[l][t], None if first else Cs[l][t], Hs[l][t + 1], above, stride, dh_state[l],
-                                  dc_state[l], x_in, None if first else Hs[l][t], packed[l],
+                    last = t == t_run - 1 and no_carry[l]
+                    ops.bwd_fused(Gs[l][t], None if first else Cs[l][t], Hs[l][t + 1], above, stride,
+                                  None if last else dh_state[l], None if last else dc_state[l], x_in,
+                                  None if first else Hs[l][t], packed[l],
                                   None if first else dc_next[l], None if first else dh_next[l], slabs[l], mode,
                                   grads[l][0], durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
                     dc_state[l], dc_next[l] = dc_next[l], dc_state[l]

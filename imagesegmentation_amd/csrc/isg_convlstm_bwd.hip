@@ -237,6 +237,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     const char* cp_base = zero_state ? static_cast<const char*>(p.gates) : reinterpret_cast<const char*>(p.c_prev);
     const char* hp_tensor = zero_state ? static_cast<const char*>(p.x) : static_cast<const char*>(p.h_prev);
     const unsigned state_mul = zero_state ? 0u : 1u, state_mask = zero_state ? 0u : 0xFFFFFFFFu;
+    // Likewise the last step of a sequence whose final state has no gradient (dh_state and dc_state null).
+    const bool no_carry = p.dh_state == nullptr;
+    const char* dhs_base = static_cast<const char*>(no_carry ? p.gates : p.dh_state);
+    const char* dcs_base = static_cast<const char*>(no_carry ? p.gates : p.dc_state);
+    const unsigned carry_mul = no_carry ? 0u : 1u, carry_mask = no_carry ? 0u : 0xFFFFFFFFu;
     const int* dur_base = p.durations != nullptr ? p.durations : reinterpret_cast<const int*>(p.gates);
     const int dur_mul = p.durations != nullptr ? 1 : 0;
     const int* hp_base = p.hist > 0 ? p.hist_points : reinterpret_cast<const int*>(p.gates);
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
                                                  (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
-        sds[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 8u));
-        sdc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 8u));
+        sds[j] = *reinterpret_cast<const uint2*>(dhs_base + (size_t)((pixel * 32u + q * 8u) * carry_mul));
+        sdc[j] = *reinterpret_cast<const uint2*>(dcs_base + (size_t)((pixel * 32u + q * 8u) * carry_mul));
     };
     auto load_x = [&](const Tile& r, auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
                     const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
                     unsigned ow[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // dY of 4 channels x 4 gates, bf16 pairs
-                    float dcp[4] = {bf_lo(sdc[j].x), bf_hi(sdc[j].x), bf_lo(sdc[j].y), bf_hi(sdc[j].y)};
+                    const unsigned dc0 = sdc[j].x & carry_mask, dc1 = sdc[j].y & carry_mask;
+                    float dcp[4] = {bf_lo(dc0), bf_hi(dc0), bf_lo(dc1), bf_hi(dc1)};
 #ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
                     if (false) {
 #else
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                                               __uint_as_float(scp[j].z & state_mask), __uint_as_float(scp[j].w & state_mask)};
                         const float hv[4] = {bf_lo(shc[j].x), bf_hi(shc[j].x), bf_lo(shc[j].y), bf_hi(shc[j].y)};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
-                        const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
+                        const unsigned ds0 = sds[j].x & carry_mask, ds1 = sds[j].y & carry_mask;
+                        const float ds[4] = {bf_lo(ds0), bf_hi(ds0), bf_lo(ds1), bf_hi(ds1)};
                         float out[16];
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
@@ -459,9 +466,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     const size_t so = (size_t)(pixel * 32u + qq * 4u);
                     if (p.dc_prev) {
                         *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
-                            *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
+                            no_carry ? 0u : *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
                         *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
-                            *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
+                            no_carry ? 0u : *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
                     }
                     if (p.dx && !p.dx_accumulate)
                         for (int ch = 2 * qq; ch < p.dx_channels; ch += 16)
@@ -886,8 +893,10 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
-    ISG_REQUIRE(gates && h_cur && x && packed_dgrad && workspace && dh_above && dh_state && dc_state, ISG_EINVAL,
+    ISG_REQUIRE(gates && h_cur && x && packed_dgrad && workspace && dh_above, ISG_EINVAL,
                 "isg_convlstm_bwd_fused: null pointer");
+    ISG_REQUIRE((dh_state == nullptr) == (dc_state == nullptr), ISG_EINVAL,
+                "isg_convlstm_bwd_fused: dh_state / dc_state are both given or both NULL (no gradient carried in)");
     ISG_REQUIRE((c_prev == nullptr) == (h_prev == nullptr) && (dc_prev == nullptr) == (dh_prev == nullptr), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: c_prev / h_prev are both given or both NULL (the step out of the zero state), "
                 "and so are dc_prev / dh_prev (NULL: not wanted)");

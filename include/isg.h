@@ -236,8 +236,9 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   close the sequence with isg_convlstm_wgrad_finish.  With hist > 0 the gradient of the history taps goes
  *   to the hist channels of dw_x (assigned / added by the same mode) through hist_scratch, device scratch of
  *   isg_convlstm_bwd_fused_hist_bytes(B, hist) bytes.
- *   dh_above, dh_state and dc_state must all be given (zeros where there is no gradient); dh_above_pool is a
- *   power of two.  c_prev and h_prev may both be NULL: the step out of the zero state (nothing is read for
+ *   dh_above must be given (zeros where there is no gradient); dh_state and dc_state may both be NULL: no
+ *   gradient is carried in (the last step of a sequence whose final state is not differentiated; nothing is
+ *   read for them).  dh_above_pool is a power of two.  c_prev and h_prev may both be NULL: the step out of the zero state (nothing is read for
  *   them; the rows of dw_h and of the h part get zero contributions).  dc_prev and dh_prev may both be NULL:
  *   the gradient of the state before this step is not wanted (nothing is written, and where the kernel has a
  *   row tile of its own for dh_prev it is skipped).  Other arguments: as the three calls it replaces. */

@@ -678,12 +678,14 @@ def test_fused_backward_step_against_float64_gate_backward():
     assert torch.equal(dh2[1], dh[1]) and torch.equal(dc2[1], dc[1]) and float(dx[1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("final_in_loss", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_first_step_out_of_the_zero_state_reads_no_state(dtype, monkeypatch):
+def test_first_step_out_of_the_zero_state_reads_no_state(dtype, final_in_loss, monkeypatch):
     """A sequence that starts from dynamic_rnn's default state tells the first step of every layer so (h_prev and
-    c_prev NULL; in the reverse sweep also dc_prev / dh_prev NULL): outputs, final states and every gradient are
-    the ones of the same sequence with the zero tensors read like any state (ISG_NO_ZERO_STATE=1) - bit for bit.
-    A sample with duration 0 passes the zero state through."""
+    c_prev NULL; in the reverse sweep also dc_prev / dh_prev NULL), and a final state that the loss does not use
+    tells the first step of the reverse sweep so (dh_state / dc_state NULL): outputs, final states and every
+    gradient are the ones of the same sequence with zero tensors read in their place (ISG_NO_ZERO_STATE=1) - bit
+    for bit.  A sample with duration 0 passes the zero state, and zero state gradients, through."""
     from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
     rs = np.random.RandomState(41)
     T, B, H, W, Cf, hist, L = 3, 4, 19, 37, 32, 1, 2
@@ -704,7 +706,9 @@ def test_first_step_out_of_the_zero_state_reads_no_state(dtype, monkeypatch):
         leaf = feat.clone().requires_grad_(True)
         out, final = dynamic_rnn(multi, SequenceInput(static=leaf, hist_points=pts), sequence_length=durations,
                                  time_major=False)
-        loss = (out.float() * d_out).sum() + sum((f.c.sum() + f.h.float().sum()) for f in final)
+        loss = (out.float() * d_out).sum()
+        if final_in_loss:
+            loss = loss + sum((f.c.sum() + f.h.float().sum()) for f in final)
         loss.backward()
         got = [out.detach().clone(), leaf.grad.clone()] + [t.detach().clone() for f in final for t in (f.c, f.h)]
         for cell in multi.cells:
