@@ -124,8 +124,13 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 }
 
 // ACC: dx is added to what the array holds (the static features' gradient over the steps of a sequence).
-template <int C0, int MT, int TR, bool PIPE, bool ACC>
+// EDGE: the two ends of a sequence as instantiations of their own (as run-time facts their scalars cost every launch
+// 2 - 4 %: a dozen more spilled scalar registers in the tile loop).  Bit 0: no gradient is carried in (dh_state and
+// dc_state null: the first step of the reverse sweep when the final state is not differentiated); bit 1: the step
+// out of the zero state (c_prev and h_prev null).  Nothing is read for a null operand; zeros take its place.
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE>
 __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
+    constexpr bool no_carry = (EDGE & 1) != 0, zero_state = (EDGE & 2) != 0;
     using K = FB<C0, MT, TR, PIPE>;
     using T = __bf16;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -231,17 +236,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         return r;
     };
     const float inv_pool = 1.0f / (float)(1 << (2 * p.pool_shift));
-    // The step out of the zero state (c_prev and h_prev null): nothing is read for either - the loads stay
-    // unconditional and re-read the first bytes of another operand - and zeros are used in their place.
-    const bool zero_state = p.c_prev == nullptr;
-    const char* cp_base = zero_state ? static_cast<const char*>(p.gates) : reinterpret_cast<const char*>(p.c_prev);
-    const char* hp_tensor = zero_state ? static_cast<const char*>(p.x) : static_cast<const char*>(p.h_prev);
-    const unsigned state_mul = zero_state ? 0u : 1u, state_mask = zero_state ? 0u : 0xFFFFFFFFu;
-    // Likewise the last step of a sequence whose final state has no gradient (dh_state and dc_state null).
-    const bool no_carry = p.dh_state == nullptr;
-    const char* dhs_base = static_cast<const char*>(no_carry ? p.gates : p.dh_state);
-    const char* dcs_base = static_cast<const char*>(no_carry ? p.gates : p.dc_state);
-    const unsigned carry_mul = no_carry ? 0u : 1u, carry_mask = no_carry ? 0u : 0xFFFFFFFFu;
+
     const int* dur_base = p.durations != nullptr ? p.durations : reinterpret_cast<const int*>(p.gates);
     const int dur_mul = p.durations != nullptr ? 1 : 0;
     const int* hp_base = p.hist > 0 ? p.hist_points : reinterpret_cast<const int*>(p.gates);
@@ -267,13 +262,18 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
         sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
         sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
-        scp[j] = *reinterpret_cast<const uint4*>(cp_base + (size_t)((pixel * 64u + q * 16u) * state_mul));
+        if constexpr (zero_state) scp[j] = make_uint4(0u, 0u, 0u, 0u);
+        else scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
         shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * 32u + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
                                                  (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
-        sds[j] = *reinterpret_cast<const uint2*>(dhs_base + (size_t)((pixel * 32u + q * 8u) * carry_mul));
-        sdc[j] = *reinterpret_cast<const uint2*>(dcs_base + (size_t)((pixel * 32u + q * 8u) * carry_mul));
+        if constexpr (no_carry) {
+            sds[j] = sdc[j] = make_uint2(0u, 0u);
+        } else {
+            sds[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 8u));
+            sdc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 8u));
+        }
     };
     auto load_x = [&](const Tile& r, auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -285,8 +285,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const unsigned pixel = (unsigned)((r.b * p.H + cy) * p.W + cx);
         const bool is_h = ch >= K::NCH0;
-        const char* base = is_h ? hp_tensor : static_cast<const char*>(p.x);
-        const unsigned off = is_h ? (pixel * (unsigned)(F_ * 2) + (unsigned)(ch - K::NCH0) * 16u) * state_mul
+        // (the zero state: an h_prev chunk re-reads the pixel's first x chunk instead - a line the x chunks bring in
+        // anyway - and the store phase writes zeros)
+        const bool from_x = !is_h || zero_state;
+        const char* base = from_x ? static_cast<const char*>(p.x) : static_cast<const char*>(p.h_prev);
+        const unsigned off = is_h ? (zero_state ? pixel * (unsigned)(C0 * 2) : pixel * (unsigned)(F_ * 2) + (unsigned)(ch - K::NCH0) * 16u)
                                   : pixel * (unsigned)(C0 * 2) + (unsigned)ch * 16u;
         sx[j] = *reinterpret_cast<const uint4*>(base + (size_t)off);
     };
@@ -366,8 +369,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                     const bool own = hy >= 1 && hy <= TR && hx >= 1 && hx <= TW;  // a pixel of the tile itself
                     const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
                     unsigned ow[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // dY of 4 channels x 4 gates, bf16 pairs
-                    const unsigned dc0 = sdc[j].x & carry_mask, dc1 = sdc[j].y & carry_mask;
-                    float dcp[4] = {bf_lo(dc0), bf_hi(dc0), bf_lo(dc1), bf_hi(dc1)};
+                    float dcp[4] = {bf_lo(sdc[j].x), bf_hi(sdc[j].x), bf_lo(sdc[j].y), bf_hi(sdc[j].y)};
 #ifdef ISG_BWD_NO_PW  // diagnostic build: the loads and the LDS traffic without the gate arithmetic
                     if (false) {
 #else
@@ -376,12 +378,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         // word 4 (ch >> 1) + k holds value k (A, B, f, o) of channels ch & ~1 (low half) and ch | 1 (high)
                         const unsigned fw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
                                                 sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
-                        const float cpv[4] = {__uint_as_float(scp[j].x & state_mask), __uint_as_float(scp[j].y & state_mask),
-                                              __uint_as_float(scp[j].z & state_mask), __uint_as_float(scp[j].w & state_mask)};
+                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
+                                              __uint_as_float(scp[j].w)};
                         const float hv[4] = {bf_lo(shc[j].x), bf_hi(shc[j].x), bf_lo(shc[j].y), bf_hi(shc[j].y)};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
-                        const unsigned ds0 = sds[j].x & carry_mask, ds1 = sds[j].y & carry_mask;
-                        const float ds[4] = {bf_lo(ds0), bf_hi(ds0), bf_lo(ds1), bf_hi(ds1)};
+                        const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
                         float out[16];
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) {
@@ -826,20 +827,31 @@ __global__ __launch_bounds__(NG) void hist_side_finish_kernel(const float* __res
     *dst = accumulate ? *dst + sum : sum;
 }
 
-template <int C0, int MT, int TR, bool PIPE, bool ACC>
-int launch_bwd_acc(BwdParams p, hipStream_t stream) {
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE>
+int launch_bwd_edge(BwdParams p, hipStream_t stream) {
     using K = FB<C0, MT, TR, PIPE>;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TR - 1) / TR;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
     const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
     const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
-    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
                        p);
     return isg::check_launch("convlstm_bwd_fused_kernel");
+}
+
+template <int C0, int MT, int TR, bool PIPE, bool ACC>
+int launch_bwd_acc(const BwdParams& p, hipStream_t stream) {
+    const int edge = (p.dh_state == nullptr ? 1 : 0) | (p.c_prev == nullptr ? 2 : 0);
+    switch (edge) {
+        case 0: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 0>(p, stream);
+        case 1: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 1>(p, stream);
+        case 2: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 2>(p, stream);
+        default: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 3>(p, stream);
+    }
 }
 
 template <int C0, int MT, int TR, bool PIPE>

@@ -84,7 +84,10 @@ struct PP {
 // EARLY: request the tile after next already in the finish phase (two phases of flight, ahead of the
 // phase's stores) instead of at the start of the compute phase (one phase of flight).  Measured at
 // 224 x 224 with the present staging code: no instantiation gains from it, so none is launched with it.
-template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
+// ZS (forward only): the step out of the zero state - in1 (h_prev) and c_prev are null, nothing is read for them and
+// zeros take their place.  An instantiation of its own: as run-time facts the few extra scalars spilled a dozen more
+// scalar registers in the loops of every launch (+2 - 7 % per launch).
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false>
 __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     using K = PP<C0, C1, MT, MODE, NPT>;
     using T = __bf16;
@@ -154,9 +157,6 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         const unsigned ldso = px * K::PSTRIDE + (K::SWZ ? chunk ^ (px & 7) : chunk) * 16;
         info[j] = ldso | (unsigned)hy << 16 | (unsigned)hx << 20 | (unsigned)chl << 26 | (exists ? 0x80000000u : 0u);
     }
-    const bool in1_zero = C1 > 0 && p.in1 == nullptr;  // forward step from the zero state (h_prev and c_prev NULL)
-    const char* in1_base = static_cast<const char*>(in1_zero ? p.in0 : p.in1);
-    const unsigned in1_mul = in1_zero ? 0u : 1u;
     auto stage_load = [&](const TileRef& r) {
         if (!r.valid) return;
         st_inside = 0u;
@@ -183,9 +183,11 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             if (j < K::NL0)
                 st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in0) +
                                                         (size_t)(pixel * (unsigned)(C0 * 2) + chunk_bytes));
-            else  // (the zero state: every lane re-reads the first bytes of in0 and stage_store writes zeros - an
-                  // unconditional load, like all the others here)
-                st[j] = *reinterpret_cast<const uint4*>(in1_base + (size_t)((pixel * (unsigned)(C1 * 2) + chunk_bytes) * in1_mul));
+            else if constexpr (ZS)
+                st[j] = make_uint4(0u, 0u, 0u, 0u);
+            else
+                st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in1) +
+                                                        (size_t)(pixel * (unsigned)(C1 * 2) + chunk_bytes));
         }
     };
     auto stage_store = [&](TileRef& r) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
         for (int j = 0; j < K::NLOAD; ++j) {
             unsigned inf = info[j];
             if constexpr (K::SWZ) asm volatile("" : "+v"(inf));  // as in stage_load
-            const bool in = ((st_inside >> j) & 1u) && !(j >= K::NL0 && in1_zero);
+            const bool in = ((st_inside >> j) & 1u) && !(ZS && j >= K::NL0);
             const uint4 v = in ? st[j] : make_uint4(0u, 0u, 0u, 0u);
             if (inf & 0x80000000u) *reinterpret_cast<uint4*>(lds_in + (inf & 0xFFFFu)) = v;
         }
@@ -281,11 +283,13 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             const int gy = min(r.ty0 + NPT * wave + pt, p.H - 1), gx = min(r.tx0 + px_l, p.W - 1);
             const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
             if constexpr (MODE == 0) {
-                // (the zero state: every lane re-reads the bias instead, and the epilogue takes zeros)
-                const uint4* src = p.c_prev ? reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half)
-                                            : reinterpret_cast<const uint4*>(p.bias);
-                pre[2 * pt] = src[0];
-                pre[2 * pt + 1] = src[1];
+                if constexpr (ZS) {
+                    pre[2 * pt] = pre[2 * pt + 1] = make_uint4(0u, 0u, 0u, 0u);  // 0.0f: the zero cell state
+                } else {
+                    const uint4* src = reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half);
+                    pre[2 * pt] = src[0];
+                    pre[2 * pt + 1] = src[1];
+                }
             } else {
                 if (p.dx && p.dx_accumulate) {
 #pragma unroll
@@ -336,11 +340,10 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 // state; gate activations leave as 16-byte stores every second channel
                 const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
                 const size_t so = pixel * F_ + 8 * half;
-                const unsigned cmask = p.c_prev ? 0xFFFFFFFFu : 0u;  // (no previous state: zeros)
-                const float cp[8] = {__uint_as_float(pre[2 * pt].x & cmask),     __uint_as_float(pre[2 * pt].y & cmask),
-                                     __uint_as_float(pre[2 * pt].z & cmask),     __uint_as_float(pre[2 * pt].w & cmask),
-                                     __uint_as_float(pre[2 * pt + 1].x & cmask), __uint_as_float(pre[2 * pt + 1].y & cmask),
-                                     __uint_as_float(pre[2 * pt + 1].z & cmask), __uint_as_float(pre[2 * pt + 1].w & cmask)};
+                const float cp[8] = {__uint_as_float(pre[2 * pt].x),     __uint_as_float(pre[2 * pt].y),
+                                     __uint_as_float(pre[2 * pt].z),     __uint_as_float(pre[2 * pt].w),
+                                     __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
+                                     __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
                 const bool factors = p.save_layout == ISG_SAVE_FACTORS;
                 T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
                 float hn[8], cn[8], gprev[4];
@@ -541,9 +544,12 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #endif
 }
 
-template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2>
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false>
 int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     using K = PP<C0, C1, MT, MODE, NPT>;
+    if constexpr (MODE == 0 && !ZS) {  // the step out of the zero state has an instantiation of its own
+        if (p0.in1 == nullptr) return launch_pp<C0, C1, MT, MODE, EARLY, NPT, true>(p0, num_cus, stream);
+    }
     static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
     if (MODE == 0 && p0.hist > 2) return kNotSupported;
     if (MODE == 0 && NPT != 2 && p0.pool_out != nullptr) return kNotSupported;
@@ -551,13 +557,13 @@ int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     if ((long long)p0.B * p0.H * p0.W * (C0 > C1 ? C0 : C1) * 2 >= (1LL << 32)) return kNotSupported;
     ConvParams p = p0;
     p.tiles_y = (p.H + K::TH_ - 1) / K::TH_;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int pairs = (ntiles + 1) / 2;
     const int grid = pairs < num_cus ? pairs : num_cus;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream,
+    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream,
                        p);
     return isg::check_launch("conv3x3_pp_kernel");
 }
