@@ -506,10 +506,13 @@ class _SequenceFunction(torch.autograd.Function):
             dc_state.append(dc.to(dt).clone().contiguous() if dc is not None else make([B, H, W, F], dtype=dt, device=dev))
             dh_state.append(dh.to(dt).clone().contiguous() if dh is not None else make([B, H, W, F], dtype=dt, device=dev))
         grads = []
+        # (every entry is assigned by the sweep - the history taps' rows by its first step, the rest by the closing
+        # fold of the partial sums - so only a sweep of no steps needs the zeros)
+        like = torch.empty_like if t_run > 0 else torch.zeros_like
         for cell in cells:
-            grads.append((torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32),
-                          torch.zeros_like(cell.hidden_to_state_kernel, dtype=torch.float32),
-                          torch.zeros_like(cell.bias, dtype=torch.float32)))
+            grads.append((like(cell.input_to_state_kernel, dtype=torch.float32),
+                          like(cell.hidden_to_state_kernel, dtype=torch.float32),
+                          like(cell.bias, dtype=torch.float32)))
         dy = torch.empty([B, H, W, F, 4], dtype=dt, device=dev)
         dx_mid = torch.empty([B, H, W, F], dtype=dt, device=dev)
         cs0 = packed[0].cs
