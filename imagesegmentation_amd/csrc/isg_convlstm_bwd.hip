@@ -80,12 +80,15 @@ struct BwdParams {
 // PIPE: three tiles in flight over two dY images (see the top of the file).  !PIPE: one dY image, every wave in the
 // same order (gate backward, store phase, phase B), two tiles in flight - what an 8-row tile of the two-row-tile
 // kernel can afford: its weight image alone is 54 - 72 KB.
-template <int C0, int MT, int TR, bool PIPE>
+// HOLD (with PIPE): the pipelined schedule on ONE dY image - the gate backward keeps its results in registers (8 per
+// pass) and they are written into the image at the join, between the two barriers, once every wave is done reading
+// the previous tile's.  For the kernel whose weight image leaves no room for a second dY image on 8-row tiles.
+template <int C0, int MT, int TR, bool PIPE, bool HOLD = false>
 struct FB {
     static constexpr int NPXH = (TR + 2) * HALO_W;       // halo tile pixels
     static constexpr int DY_PSTRIDE = NG * 2 + 16;       // padded pixel stride of the halo dY image
     static constexpr int DYH_BYTES = NPXH * DY_PSTRIDE;
-    static constexpr int NDY = PIPE ? 2 : 1;             // dY images
+    static constexpr int NDY = PIPE && !HOLD ? 2 : 1;    // dY images
     static constexpr int RSTRIDE = 64;                   // 32 channels: one region row of the [x | h_prev] image
     static constexpr int IN_REGION = NPXH * RSTRIDE;
     static constexpr int IN_BYTES = MT * IN_REGION;
@@ -107,6 +110,11 @@ struct FB {
     static constexpr bool HMERGE = MT == 2 && C0 + F_ <= 48;
     static constexpr int NWT = MT == 1 ? 9 : HMERGE ? 14 : 18;
     static constexpr int NSLOT = (NWT + 3) / 4;          // tiles per wave (4 wave pairs share them)
+    // With stacked h rows the last tile's upper 16 rows have no tap: they are fed ones instead, and every one of
+    // them then holds the sum of dY over the pixels - the bias gradient - at the price of four selects per k-step
+    // on one wave pair; the other kernels sum it in the gate backward's registers (16 per thread).
+    static constexpr bool BIAS_MFMA = HMERGE;
+    static constexpr int BIAS_TILE = 13, BIAS_GROUP = 3, BIAS_SLOT = 2;  // where that tile sits (see the dealing below)
     static constexpr int NMT = TR * MT / 8;              // row tiles of ONE tile row a wave takes in the data gradient
     static_assert(TR * MT == 8 || (TR == 8 && MT == 2), "data-gradient units (tile row x row tile) per wave: 1 or 2");
     static_assert(C0 + F_ <= MT * 32 && C0 % 8 == 0, "input channels must fit the row tiles");
@@ -128,10 +136,10 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 // 2 - 4 %: a dozen more spilled scalar registers in the tile loop).  Bit 0: no gradient is carried in (dh_state and
 // dc_state null: the first step of the reverse sweep when the final state is not differentiated); bit 1: the step
 // out of the zero state (c_prev and h_prev null).  Nothing is read for a null operand; zeros take its place.
-template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE>
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD = false>
 __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
     constexpr bool no_carry = (EDGE & 1) != 0, zero_state = (EDGE & 2) != 0;
-    using K = FB<C0, MT, TR, PIPE>;
+    using K = FB<C0, MT, TR, PIPE, HOLD>;
     using T = __bf16;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     (void)sizeof(s16x8);
@@ -300,6 +308,9 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     constexpr int kBase = K::NWT / 4, kExtra = K::NWT % 4;
     const int wg_first = wg_grp * kBase + min(wg_grp, kExtra), wg_cnt = kBase + (wg_grp < kExtra ? 1 : 0);
     const bool wg_full = wg_cnt == K::NSLOT;  // the last slot is used by the larger groups only
+    static_assert(!K::BIAS_MFMA || (K::NWT == 14 && kBase == 3 && kExtra == 2), "the ones-fed tile is tile 13 = slot 2 of group 3");
+    // (lanes 16-31 and 48-63 feed rows 16-31 of the A operand)
+    const bool ones_rows = K::BIAS_MFMA && wg_grp == K::BIAS_GROUP && ((lane >> 4) & 1) != 0;
     f32x16 wacc[K::NSLOT];
 #pragma unroll
     for (int i = 0; i < K::NSLOT; ++i)
@@ -348,6 +359,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     // take the gate backward first, waves 4-7 phase B first, and on every SIMD one wave's vector arithmetic runs
     // under the other's MFMAs.  A short store phase after the closing barrier writes the [x | h_prev] tile of
     // tile n + 1 (in registers since the interval before) over that of tile n.
+    uint4 hold[HOLD ? K::NPW : 1][2];  // HOLD: the last gate backward's dY, on its way into the image
+    bool hold_live = false;
     bool m_live = false;     // facts of the tile the last gate backward worked on, taken from the staging words
     int m_hp[4] = {-1, 0, -1, 0};
 
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const unsigned inside_bits = pw_inside;
         pw_inside = 0u;
         load_meta(req);
+        hold_live = m_live;
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 constexpr int j = I;
@@ -402,16 +416,22 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                             dcp[ch] = dct * fg;
                         }
                         // the bias gradient: dY summed over the pixels this tile owns (halo pixels belong to a neighbour)
-                        const float ownf = own ? 1.0f : 0.0f;
+                        if constexpr (!K::BIAS_MFMA) {
+                            const float ownf = own ? 1.0f : 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) bacc[i] = fmaf(ownf, out[i], bacc[i]);
+                            for (int i = 0; i < 16; ++i) bacc[i] = fmaf(ownf, out[i], bacc[i]);
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) ow[i] = pack_bf2(out[2 * i], out[2 * i + 1]);
                     }
                     const uint4 o0 = make_uint4(ow[0], ow[1], ow[2], ow[3]), o1 = make_uint4(ow[4], ow[5], ow[6], ow[7]);
-                    char* dh_dst = dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
-                    *reinterpret_cast<uint4*>(dh_dst) = o0;
-                    *reinterpret_cast<uint4*>(dh_dst + 16) = o1;
+                    if constexpr (HOLD) {
+                        hold[j][0] = o0, hold[j][1] = o1;
+                    } else {
+                        char* dh_dst = dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
+                        *reinterpret_cast<uint4*>(dh_dst) = o0;
+                        *reinterpret_cast<uint4*>(dh_dst + 16) = o1;
+                    }
                     if (own && inside) {
                         const unsigned pixel = (unsigned)((c.b * p.H + gy) * p.W + gx);
                         if (p.dc_prev)  // (null: nobody wants the gradient of the state before this step)
@@ -434,6 +454,27 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 load_pw(req, std::integral_constant<int, j>{});
             }(), ...);
         }(std::make_integer_sequence<int, K::NPW>{});
+    };
+
+    // HOLD: the held dY of the last gate backward into the (one) image; called where no wave reads the image
+    auto flush_hold = [&]() __attribute__((always_inline)) {
+        if constexpr (HOLD) {
+            if (hold_live) {
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    ([&] {
+                        constexpr int j = I;
+                        int inf = pinfo[j];
+                        asm volatile("" : "+v"(inf));
+                        if (inf < 0) {
+                            const int hy = inf & 0xff, hx = (inf >> 8) & 0xff;
+                            char* dh_dst = lds_dyh + (hy * HALO_W + hx) * K::DY_PSTRIDE + q * 32;
+                            *reinterpret_cast<uint4*>(dh_dst) = hold[j][0];
+                            *reinterpret_cast<uint4*>(dh_dst + 16) = hold[j][1];
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, K::NPW>{});
+            }
+        }
     };
 
     // Store phase of tile `c`: its [x | h_prev] chunks (in sx) into the LDS image, then (pipelined schedule) the
@@ -531,8 +572,16 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 bq[slot] = tr_pair(dyb + (r * HALO_W + x0) * K::DY_PSTRIDE, std::integral_constant<int, K::DY_PSTRIDE>{});
 #pragma unroll
                 for (int i = 0; i < K::NSLOT; ++i)
-                    if (i < K::NSLOT - 1 || wg_full)
+                    if (i < K::NSLOT - 1 || wg_full) {
                         aq[slot][i] = tr_pair(wg_in[i] + (r * HALO_W + x0) * K::RSTRIDE, std::integral_constant<int, K::RSTRIDE>{});
+                        if constexpr (K::BIAS_MFMA) {
+                            if (i == K::BIAS_SLOT) {  // 1.0 in bf16, eight times
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+                                aq[slot][i] = ones_rows ? __builtin_bit_cast(bf16x8, ones) : aq[slot][i];
+                            }
+                        }
+                    }
             };
             if constexpr (NBUF == 2) fetch(0, 0);
 #pragma unroll
@@ -697,7 +746,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             BSTAMP(s6);
             __syncthreads();
             BSTAMP(s7);
-            cur = nxt, nxt = nxt2, cur_live = m_live, cur_buf ^= 1;
+            cur = nxt, nxt = nxt2, cur_live = m_live, cur_buf ^= K::NDY - 1;
+            flush_hold();
             store_phase(cur, cur_live, nxt);
             BSTAMP(s8);
             __syncthreads();
@@ -711,13 +761,14 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // 0-3 join after phase B: their interval is [gate backward of tile k + 1, phase B of tile k].  Waves 4-7
         // join between the two, so that phase B of a pass already works on tile k + 1: their interval is [phase B
         // of tile k, gate backward of tile k + 1].  Every wave passes the same number of barriers.
+        flush_hold();
         store_phase(cur, cur_live, nxt);
         __syncthreads();  // (also the weight image)
         if (!m_first) run_b();
         for (int k = 0; k < n_iter; ++k) {
             nxt2 = tile_ref(k + 2);
             BSTAMP(s1c);
-            gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ 1) * K::DYH_BYTES);
+            gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ (K::NDY - 1)) * K::DYH_BYTES);
             BSTAMP(s1d);
             BSTAMP_ADD(2, s1c, s1d);  // gate backward of the next tile
             if (m_first) run_b();
@@ -780,6 +831,15 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             }
         }
     }
+    if constexpr (K::BIAS_MFMA) {
+        // register 8 of the ones-fed tile = its row 16 + 4 half: the bias sums of this wave's 32 dY columns
+        if (wg_grp == K::BIAS_GROUP && half == 0) {
+            float* dst = p.bias_slab + (size_t)blockIdx.x * NG + 32 * wg_n + lane;
+            const float v = wacc[K::BIAS_SLOT][8];
+            *dst = p.slab_accumulate ? *dst + v : v;
+        }
+        return;
+    }
     // the bias sums of the 128 threads that share q, through LDS (every wave is past its last tile), in a fixed order
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds_dyh);
@@ -827,38 +887,38 @@ __global__ __launch_bounds__(NG) void hist_side_finish_kernel(const float* __res
     *dst = accumulate ? *dst + sum : sum;
 }
 
-template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE>
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD>
 int launch_bwd_edge(BwdParams p, hipStream_t stream) {
-    using K = FB<C0, MT, TR, PIPE>;
+    using K = FB<C0, MT, TR, PIPE, HOLD>;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TR - 1) / TR;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
     const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
     const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
-    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
                        p);
     return isg::check_launch("convlstm_bwd_fused_kernel");
 }
 
-template <int C0, int MT, int TR, bool PIPE, bool ACC>
+template <int C0, int MT, int TR, bool PIPE, bool ACC, bool HOLD>
 int launch_bwd_acc(const BwdParams& p, hipStream_t stream) {
     const int edge = (p.dh_state == nullptr ? 1 : 0) | (p.c_prev == nullptr ? 2 : 0);
     switch (edge) {
-        case 0: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 0>(p, stream);
-        case 1: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 1>(p, stream);
-        case 2: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 2>(p, stream);
-        default: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 3>(p, stream);
+        case 0: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 0, HOLD>(p, stream);
+        case 1: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 1, HOLD>(p, stream);
+        case 2: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 2, HOLD>(p, stream);
+        default: return launch_bwd_edge<C0, MT, TR, PIPE, ACC, 3, HOLD>(p, stream);
     }
 }
 
-template <int C0, int MT, int TR, bool PIPE>
+template <int C0, int MT, int TR, bool PIPE, bool HOLD = false>
 int launch_bwd(const BwdParams& p, int num_cus, hipStream_t stream) {
     (void)num_cus;
-    return p.dx != nullptr && p.dx_accumulate ? launch_bwd_acc<C0, MT, TR, PIPE, true>(p, stream)
-                                             : launch_bwd_acc<C0, MT, TR, PIPE, false>(p, stream);
+    return p.dx != nullptr && p.dx_accumulate ? launch_bwd_acc<C0, MT, TR, PIPE, true, HOLD>(p, stream)
+                                             : launch_bwd_acc<C0, MT, TR, PIPE, false, HOLD>(p, stream);
 }
 
 int bwd_num_cus() {
@@ -952,9 +1012,15 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
              : Cs == 32 ? launch_bwd<32, 2, 4, true>(p, bwd_num_cus(), s)
                         : launch_bwd<48, 2, 4, true>(p, bwd_num_cus(), s);
 #else
+#ifdef ISG_BWD_L0_NOHOLD  // diagnostic build: the 48-row kernel on the schedule without overlap
     int rc = Cs == 16   ? launch_bwd<16, 1, 8, true>(p, bwd_num_cus(), s)
              : Cs == 32 ? launch_bwd<32, 2, 8, false>(p, bwd_num_cus(), s)
                         : launch_bwd<48, 2, 4, true>(p, bwd_num_cus(), s);
+#else
+    int rc = Cs == 16   ? launch_bwd<16, 1, 8, true>(p, bwd_num_cus(), s)
+             : Cs == 32 ? launch_bwd<32, 2, 8, true, true>(p, bwd_num_cus(), s)
+                        : launch_bwd<48, 2, 4, true>(p, bwd_num_cus(), s);
+#endif
 #endif
     if (rc != ISG_OK) return rc;
     if (hist > 0) {
