@@ -64,8 +64,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w_x, const float* 
                 const int ch = kc >> 2, gate = kc & 3;  // dY channel order: [channel][gate]
                 const int col = gate * F_ + ch;
                 const int ftap = 8 - tap;               // flipped tap
-                if (R < C) v = w_x[((size_t)ftap * Cw + R) * NG + col];
-                else if (R >= Cs && R < Cs + F_) v = w_h[((size_t)ftap * F_ + (R - Cs)) * NG + col];
+                const int ci = dgrad_row_to_channel(R);
+                if (ci < C) v = w_x[((size_t)ftap * Cw + ci) * NG + col];
+                else if (ci >= Cs && ci < Cs + F_) v = w_h[((size_t)ftap * F_ + (ci - Cs)) * NG + col];
             }
         }
         out[idx] = Tr<T>::from_f(v);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(ConvParams p) {
                     for (int a = 0; a < 4; ++a) {
                         float v[4] = {acc[t][pt][4 * a], acc[t][pt][4 * a + 1], acc[t][pt][4 * a + 2],
                                       acc[t][pt][4 * a + 3]};
-                        dgrad_store4<T>(p, pixel, p.row_base + 32 * t + 8 * a + 4 * half, v);
+                        dgrad_store4<T>(p, pixel, dgrad_frag_channel(p.row_base + 32 * t, a, half), v);
                     }
             }
         }

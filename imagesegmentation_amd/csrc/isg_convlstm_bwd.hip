@@ -536,19 +536,35 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // Requested by every lane of an accumulating launch, on every path (a lane whose channels lie past
         // dx_channels re-reads the first bytes of dx and drops them): a load under a condition is one the compiler
         // cannot count, and it then waits for everything in flight wherever the register comes up again.
-        constexpr bool accumulate = ACC;  // (the host picks the instantiation: p.dx != null and p.dx_accumulate)
+        // (ACC: the host picks the instantiation, p.dx != null and p.dx_accumulate)
         const char* pre_base = static_cast<const char*>(p.dx);
-        uint2 pre[K::NMT][4];
+        // Row tile 0 of the weight image is stored permuted (dgrad_row_to_channel): a lane's 16 accumulator registers
+        // are channels 16 half .. 16 half + 15, two 16-byte pieces.  A wave whose row tile is a later one has four
+        // 8-byte pieces (channels 8 a + 4 half .. + 3 of the tile).
+        uint4 pre[K::NMT][2];
         if constexpr (ACC) {
 #pragma unroll
-            for (int u = 0; u < K::NMT; ++u)
+            for (int u = 0; u < K::NMT; ++u) {
+                const int row0 = 32 * (dg_mt + u);
 #pragma unroll
-                for (int a4 = 0; a4 < 4; ++a4) {
-                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
-                    const bool has = cc0 < C0 && cc0 < p.dx_channels;
-                    if (32 * u + 8 * a4 < C0 || K::NMT == 1)  // (compile-time: row groups that can hold dx channels at all)
-                        pre[u][a4] = *reinterpret_cast<const uint2*>(pre_base + (size_t)(has ? dx_off + (unsigned)(cc0 * 2) : 0u));
-                }
+                for (int q = 0; q < 2; ++q)
+                    if (32 * u + 16 * q < C0 || K::NMT == 1) {  // (compile-time: row groups that can hold dx channels at all)
+                        if (row0 == 0) {
+                            const int cc0 = 16 * half + 8 * q;
+                            const bool has = cc0 < C0 && cc0 < p.dx_channels;
+                            pre[u][q] = *reinterpret_cast<const uint4*>(pre_base + (size_t)(has ? dx_off + (unsigned)(cc0 * 2) : 0u));
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int cc0 = row0 + 8 * (2 * q + k) + 4 * half;
+                                const bool has = cc0 < C0 && cc0 < p.dx_channels;
+                                const uint2 v = *reinterpret_cast<const uint2*>(pre_base + (size_t)(has ? dx_off + (unsigned)(cc0 * 2) : 0u));
+                                if (k == 0) pre[u][q].x = v.x, pre[u][q].y = v.y;
+                                else pre[u][q].z = v.x, pre[u][q].w = v.y;
+                            }
+                        }
+                    }
+            }
         }
         // (the weight gradient first: what the data gradient's epilogue waits for - the old dx values, and with
         // them every load requested before them - then has the whole of phase B to arrive)
@@ -636,26 +652,50 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #endif
             // The old dx values are added to ALL accumulators before the first store goes out: a store between two
             // of these uses would make the wait for the next old value also wait for that store's completion (the
-            // counter is in order), one memory round trip per 8 bytes of dx.
+            // counter is in order), one memory round trip per piece of dx.
+            const int row0 = 32 * (dg_mt + u);
+            if constexpr (ACC) {
 #pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                if (ACC && (32 * u + 8 * a4 < C0 || K::NMT == 1)) {
-                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
-                    const bool has = accumulate && cc0 < C0 && cc0 < p.dx_channels;
-                    const uint2 o = pre[u][a4];
-                    acc[4 * a4] += has ? bf_lo(o.x) : 0.0f, acc[4 * a4 + 1] += has ? bf_hi(o.x) : 0.0f;
-                    acc[4 * a4 + 2] += has ? bf_lo(o.y) : 0.0f, acc[4 * a4 + 3] += has ? bf_hi(o.y) : 0.0f;
-                }
+                for (int q = 0; q < 2; ++q)
+                    if (32 * u + 16 * q < C0 || K::NMT == 1) {
+                        const uint4 o = pre[u][q];
+                        const unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int cc0 = row0 == 0 ? 16 * half + 8 * q : row0 + 8 * (2 * q + k) + 4 * half;
+                            const bool has = cc0 < C0 && cc0 < p.dx_channels;
+                            const int r0 = 8 * q + 4 * k;
+                            acc[r0] += has ? bf_lo(w[2 * k]) : 0.0f, acc[r0 + 1] += has ? bf_hi(w[2 * k]) : 0.0f;
+                            acc[r0 + 2] += has ? bf_lo(w[2 * k + 1]) : 0.0f, acc[r0 + 3] += has ? bf_hi(w[2 * k + 1]) : 0.0f;
+                        }
+                    }
             }
             // (the sums exist HERE, in registers: without this the additions sink into the conditional stores below)
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[r]));
             __builtin_amdgcn_sched_barrier(0);
-            if (e_in) {
+            if (row0 == 0) {
+                // 16 consecutive channels per lane, all of them x channels or all of them h_prev channels (C0 is a
+                // multiple of 16): the destination is picked per lane and both halves of the wave store together
+                const bool to_dx = C0 >= 32 || half == 0;
+                char* dst = to_dx ? static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(32 * half))
+                                  : static_cast<char*>(p.dh_prev) + (size_t)(epixel_u * (unsigned)(F_ * 2) + (unsigned)(32 * half - 2 * C0));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cc0 = 16 * half + 8 * q;
+                    const bool ok = to_dx ? (p.dx != nullptr && cc0 < p.dx_channels) : (p.dh_prev != nullptr && cc0 < C0 + F_);
+                    if (e_in && ok) {
+                        uint4 o;
+                        o.x = pack_bf2(acc[8 * q], acc[8 * q + 1]), o.y = pack_bf2(acc[8 * q + 2], acc[8 * q + 3]);
+                        o.z = pack_bf2(acc[8 * q + 4], acc[8 * q + 5]), o.w = pack_bf2(acc[8 * q + 6], acc[8 * q + 7]);
+                        *reinterpret_cast<uint4*>(dst + 16 * q) = o;
+                    }
+                }
+            } else if (e_in) {
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
                     float v[4] = {acc[4 * a4], acc[4 * a4 + 1], acc[4 * a4 + 2], acc[4 * a4 + 3]};
-                    const int cc0 = 32 * (dg_mt + u) + 8 * a4 + 4 * half;
+                    const int cc0 = row0 + 8 * a4 + 4 * half;
                     if (cc0 < C0) {
                         if (p.dx && cc0 < p.dx_channels)
                             store4(reinterpret_cast<T*>(static_cast<char*>(p.dx) + (size_t)(dx_off + (unsigned)(cc0 * 2))), v);
@@ -985,9 +1025,9 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
                 "isg_convlstm_bwd_fused: dx is addressed with 32-bit byte offsets");
     int pool_shift = 0;
     while ((1 << pool_shift) < dh_above_pool) ++pool_shift;
-    ISG_REQUIRE(!dx || (dx_channels >= 4 && dx_channels % 4 == 0 && dx_channels <= Cs && dx_channel_stride % 4 == 0 &&
+    ISG_REQUIRE(!dx || (dx_channels >= 8 && dx_channels % 8 == 0 && dx_channels <= Cs && dx_channel_stride % 8 == 0 &&
                         dx_channel_stride >= dx_channels),
-                ISG_EINVAL, "isg_convlstm_bwd_fused: dx channels/stride must be multiples of 4 within the input width");
+                ISG_EINVAL, "isg_convlstm_bwd_fused: dx channels/stride must be multiples of 8 within the input width");
     ISG_REQUIRE(hist == 0 || (hist_points && hist_scratch && dw_x), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: history points, scratch and dw_x are needed when hist > 0");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                     for (int t = 0; t < MT; ++t)
 #pragma unroll
                         for (int a4 = 0; a4 < 4; ++a4) {
-                            const int cc0 = p.row_base + 32 * t + 8 * a4 + 4 * half;
+                            const int cc0 = dgrad_frag_channel(p.row_base + 32 * t, a4, half);
                             uint2 v = make_uint2(0u, 0u);
                             if (cc0 < p.row_split && cc0 < p.dx_channels)
                                 v = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.dx) + pixel * p.dx_cstride + cc0);
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                     for (int a4 = 0; a4 < 4; ++a4) {
                         float v[4] = {acc[t][pt][4 * a4], acc[t][pt][4 * a4 + 1], acc[t][pt][4 * a4 + 2],
                                       acc[t][pt][4 * a4 + 3]};
-                        const int cc0 = p.row_base + 32 * t + 8 * a4 + 4 * half;
+                        const int cc0 = dgrad_frag_channel(p.row_base + 32 * t, a4, half);
                         if (p.dx && p.dx_accumulate && cc0 < p.row_split && cc0 < p.dx_channels) {
                             const uint2 o = pre[(pt * MT + t) * 4 + a4];
                             v[0] += __uint_as_float(o.x << 16), v[1] += __uint_as_float(o.x & 0xFFFF0000u);

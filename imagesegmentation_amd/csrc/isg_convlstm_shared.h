@@ -73,6 +73,20 @@ __host__ __device__ inline int fwd_row_to_col(int R) {
     return gate * F_ + 8 * hh + 4 * t + a;
 }
 
+// Input channel of the [x | h_prev] concatenation held by row R of the data-gradient weight image.  The first 32-row
+// tile is stored permuted: the 16 accumulator registers of an MFMA lane (rows 8 a + 4 half + i, a = 0..3, i = 0..3)
+// are then the 16 CONSECUTIVE channels 16 half + 4 a + i, which an epilogue stores as two 16-byte pieces instead of
+// four 8-byte ones.  Later row tiles keep the identity (the fused backward reads the second one through a 16-row
+// MFMA whose lanes already hold consecutive channels).
+__host__ __device__ inline int dgrad_row_to_channel(int R) {
+    return R < 32 ? 16 * ((R >> 2) & 1) + 4 * (R >> 3) + (R & 3) : R;
+}
+// First of the four consecutive channels in accumulator registers 4 a .. 4 a + 3 of a lane in half `half` of the
+// wave, for the row tile that starts at image row `row0` (a multiple of 32).
+__device__ __forceinline__ int dgrad_frag_channel(int row0, int a, int half) {
+    return row0 == 0 ? 16 * half + 4 * a : row0 + 8 * a + 4 * half;
+}
+
 struct ConvParams {
     const void* in0;  // [B,H,W,c0]
     const void* in1;  // [B,H,W,c1] or null (c1 = 0)
