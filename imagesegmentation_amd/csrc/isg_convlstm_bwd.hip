@@ -17,10 +17,14 @@
 // Pipelined schedule (PIPE): three tiles are in flight - there are TWO dY images, so the gate backward of tile
 // n + 1 (vector ALU) runs while phase B of tile n (matrix pipe) reads the other image, in opposite order on the two
 // waves of every SIMD, and the operands of tile n + 2 are requested into each staging register as the gate
-// backward frees it.  The 48-row kernel (two row tiles, a 54 - 72 KB weight image) has LDS for one dY image on
-// 8-row tiles only: there every wave runs the three parts in order, with the next tile's operands in flight.
-// What bounds it: the vector ALU (unpacking, addressing and converting around the gate arithmetic) with
-// ~600 - 800 bytes per pixel in flight behind it.
+// backward frees it.  The 48-row kernel of the first layer (32 x channels + 16 h_prev channels, a 54 KB weight image)
+// has LDS for ONE dY image on 8-row tiles: it runs the same schedule with the gate backward's dY held in registers
+// until the join (HOLD), where no wave reads the image any more.  Its data gradient takes the 48 rows as three
+// 16-row tiles on 16 x 16 x 32 MFMAs, so that every dY fragment is read from LDS once for all of them, and the
+// operands of the last gate-backward pass are requested after phase B (DEFER_LAST) - without that the kernel does
+// not fit its 256 registers.  The 64-row kernel (48 x channels) runs the three parts in order on 4-row tiles.
+// What bounds it: LDS delivery in phase B (both k-loops read ~2 KB of fragments per MFMA; the matrix pipe idles
+// about half the time) and the vector ALU in the gate backward, with ~600 - 800 bytes per pixel in flight behind them.
 #include <utility>
 
 #include "isg_convlstm_shared.h"
@@ -96,6 +100,7 @@ struct FB {
     // Rows C0 + F .. 63 of the second row tile are padding whose results nobody stores: when they are the tile's
     // upper 16 rows, only its lower 16 are kept in LDS (lanes of the upper rows read the lower rows' fragments).
     static constexpr bool WCOMPACT = MT == 2 && TR == 8 && C0 + F_ <= 48;  // (the wave then owns both row tiles)
+    static constexpr bool DEFER_LAST = WCOMPACT && PIPE;      // (see request_last_pass in the kernel)
     static constexpr int W1_STEP = WCOMPACT ? 512 : 1024;     // bytes per k-step of the second row tile
     static constexpr int W_BYTES = NS * 1024 + (MT == 2 ? NS * W1_STEP : 0);
     static constexpr int OFF_DYH = W_BYTES, OFF_IN = OFF_DYH + NDY * DYH_BYTES;
@@ -157,11 +162,17 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         if constexpr (!K::WCOMPACT) {
             for (int i = tid; i < K::W_BYTES / 16; i += kBwdThreads) dst[i] = src[i];
         } else {
-            for (int i = tid; i < K::NS * 64; i += kBwdThreads) dst[i] = src[i];
-            // second row tile: fragment (k-step s, k half kg, row m < 16) -> 16-byte slot s * 32 + kg * 16 + m
-            for (int i = tid; i < K::NS * 32; i += kBwdThreads) {
-                const int sidx = i >> 5, kg = (i >> 4) & 1, m = i & 15;
-                dst[K::NS * 64 + i] = src[(K::NS + sidx) * 64 + kg * 32 + m];
+            // Three 16-row tiles in the A layout of the 16 x 16 x 32 MFMA: fragment (32-deep k-step s32, lane l) =
+            // row l % 16, k = 8 (l / 16) .. + 7, a 16-byte slot at (s32 * 64 + l) * 16 of the tile.  Tiles 0 and 1
+            // are the x rows, row 4 q + i of tile j = channel 8 q + 4 j + i (a lane's accumulators of the two tiles
+            // are then 8 consecutive channels); tile 2 is the h_prev rows in order.  The source fragments are those of
+            // the 32-row image: 16-deep k-step 2 s32 + (l / 32), k half (l / 16) % 2, row as stored there.
+            for (int i = tid; i < 3 * K::NS * 32; i += kBwdThreads) {
+                const int j = i / (K::NS * 32), r = i - j * (K::NS * 32);
+                const int sidx = r >> 5, kg = (r >> 4) & 1, m = r & 15;
+                const int c = 8 * (m >> 2) + 4 * j + (m & 3);                 // x channel (tiles 0, 1)
+                const int prow = 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3);  // its row of the permuted first tile
+                dst[i] = j < 2 ? src[sidx * 64 + kg * 32 + prow] : src[(K::NS + sidx) * 64 + kg * 32 + m];
             }
         }
         if constexpr (C0 + F_ < MT * 32) {
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         }
                     }
                 }
-                load_pw(req, std::integral_constant<int, j>{});
+                if constexpr (!(K::DEFER_LAST && j == K::NPW - 1)) load_pw(req, std::integral_constant<int, j>{});
             }(), ...);
         }(std::make_integer_sequence<int, K::NPW>{});
     };
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 
     // phase B of tile `c`: data gradient of this wave's tile row (+ its stores), then the weight gradient
     auto phase_b = [&](int dyo, bool e_in, unsigned epixel_u, int tb, int ty0, int tx0) __attribute__((always_inline)) {
-        (void)tb, (void)ty0, (void)tx0;
+        (void)tb, (void)ty0, (void)tx0, (void)e_in, (void)epixel_u;
         BSTAMP(s2);
         // (32-bit byte offsets from the tensors' bases, as everywhere in this kernel: the bases then stay in scalar
         // registers instead of vector register pairs)
@@ -542,7 +553,31 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // are channels 16 half .. 16 half + 15, two 16-byte pieces.  A wave whose row tile is a later one has four
         // 8-byte pieces (channels 8 a + 4 half .. + 3 of the tile).
         uint4 pre[K::NMT][2];
-        if constexpr (ACC) {
+        // (the kernel on 16-row tiles: lane l holds pixels 16 hh + l % 16 of the tile row, x channels 8 (l / 16) .. + 7)
+        const int l16 = lane & 15, kb = lane >> 4;
+        unsigned cdx_off[2];
+        bool c_in[2];
+        if constexpr (K::WCOMPACT) {
+            const int gy2 = ty0 + dg_row;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int gx2 = tx0 + 16 * hh + l16;
+                c_in[hh] = gy2 < p.H && gx2 < p.W;
+                const unsigned pixel = (unsigned)((tb * p.H + min(gy2, p.H - 1)) * p.W + min(gx2, p.W - 1));
+                cdx_off[hh] = pixel * (unsigned)(p.dx_cstride * 2) + (unsigned)(kb * 16);
+            }
+        }
+        // (requested after the weight gradient's k-loop, whose fragment buffers need the registers; the data
+        // gradient's k-loop is time enough for them to arrive)
+        auto request_pre_compact = [&]() __attribute__((always_inline)) {
+            if constexpr (ACC && K::WCOMPACT) {
+                const bool has = 8 * kb < p.dx_channels;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    pre[0][hh] = *reinterpret_cast<const uint4*>(pre_base + (size_t)(has ? cdx_off[hh] : 0u));
+            }
+        };
+        if constexpr (ACC && !K::WCOMPACT) {
 #pragma unroll
             for (int u = 0; u < K::NMT; ++u) {
                 const int row0 = 32 * (dg_mt + u);
@@ -618,10 +653,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 #endif
         BSTAMP(s4);
         BSTAMP_ADD(4, s2, s4);  // weight-gradient k-loop
+        request_pre_compact();
         // (a wave with two row tiles of its tile row takes them one after the other: both at once would need a second
         // set of accumulators the kernel has no registers for; the dY fragments are read again instead)
 #pragma unroll
-        for (int u = 0; u < (K::WCOMPACT ? 1 : K::NMT); ++u) {
+        for (int u = 0; u < (K::WCOMPACT ? 0 : K::NMT); ++u) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -705,49 +741,95 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                 }
             }
         }
-        if constexpr (K::WCOMPACT) if (p.dh_prev != nullptr) {  // (this row tile is dh_prev alone: skipped when nobody wants it)
-            // The second row tile holds 16 real rows (h_prev's channels): 16 x 16 x 32 MFMAs, two per 32-deep k-step
-            // (pixels 0-15 and 16-31 of the tile row), half the matrix-pipe time of a 32-row tile that is half
-            // padding.  The compact weight image is already in this instruction's A layout: lane l reads 16 bytes
-            // at l * 16 of each 1 KB k-step (row l % 16, k = 8 (l / 16) .. + 7).
+        if constexpr (K::WCOMPACT) {
+            // 48 real rows (32 x channels, 16 h_prev channels) as three 16-row tiles on 16 x 16 x 32 MFMAs, two per
+            // tile and 32-deep k-step (pixels 0-15 and 16-31 of the tile row).  Against a 32-row tile plus a 16-row
+            // one this reads each dY fragment once for all 48 rows: 5 KB of LDS per k-step and wave instead of 7, in a
+            // kernel whose phases are bounded by what LDS delivers.  The weight image is in the instruction's A
+            // layout: lane l reads 16 bytes at l * 16 of each 1 KB k-step (row l % 16, k = 8 (l / 16) .. + 7).
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4 acc2[2];
+            f32x4 acc2[3][2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) acc2[hh] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const int l16 = lane & 15, kb = lane >> 4;
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) acc2[j][hh] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const bool want_dh = p.dh_prev != nullptr;  // (the third tile is dh_prev alone: skipped when nobody wants it)
 #ifndef ISG_BWD_NO_DGRAD
             {
                 const char* bb = lds_dyh + dyo + (dg_row * HALO_W + l16) * K::DY_PSTRIDE + kb * 16;
-                const char* aw = lds_w + K::NS * 1024 + lane * 16;
-                bf16x8 a[2], b[2][2];
-                auto fetch = [&](int s32, int slot) {
+                const char* aw = lds_w + lane * 16;
+                // (dY fragments double-buffered; a weight fragment is requested again as soon as its two MFMAs of this
+                // k-step have issued - one register set for the three of them)
+                bf16x8 a[3], b[2][2];
+                auto fetch_a = [&](int s32, int j) {
+                    a[j] = *reinterpret_cast<const bf16x8*>(aw + j * (K::NS * 512) + s32 * 1024);
+                };
+                auto fetch_b = [&](int s32, int slot) {
                     const int tap = s32 >> 1;
-                    a[slot] = *reinterpret_cast<const bf16x8*>(aw + s32 * 1024);
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
                         b[slot][hh] = *reinterpret_cast<const bf16x8*>(
                             bb + ((tap / 3) * HALO_W + (tap % 3) + 16 * hh) * K::DY_PSTRIDE + (s32 & 1) * 64);
                 };
-                fetch(0, 0);
+                fetch_b(0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < 2 || want_dh) fetch_a(0, j);
 #pragma unroll
                 for (int s32 = 0; s32 < K::NS / 2; ++s32) {
-                    if (s32 + 1 < K::NS / 2) fetch(s32 + 1, (s32 + 1) & 1);
+                    if (s32 + 1 < K::NS / 2) fetch_b(s32 + 1, (s32 + 1) & 1);
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh)
-                        acc2[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s32 & 1], b[s32 & 1][hh], acc2[hh], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < 3; ++j)
+                        if (j < 2 || want_dh) {
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh)
+                                acc2[j][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[s32 & 1][hh], acc2[j][hh], 0, 0, 0);
+                            if (s32 + 1 < K::NS / 2) fetch_a(s32 + 1, j);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                 }
             }
 #endif
-            // lane l: pixel 16 hh + l % 16 of the tile row, h_prev channels 4 (l / 16) .. + 3
-            const int gy2 = ty0 + dg_row;
+            // lane l: pixel 16 hh + l % 16 of the tile row; x channels 8 (l / 16) .. + 7 (tiles 0 and 1), h_prev
+            // channels 4 (l / 16) .. + 3 (tile 2).  The old dx values are added to all accumulators before the first
+            // store goes out (the memory counter is in order).
+            float dxv[2][8];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const int gx2 = tx0 + 16 * hh + l16;
-                if (gy2 < p.H && gx2 < p.W) {
-                    const unsigned pixel = (unsigned)((tb * p.H + gy2) * p.W + gx2);
-                    float v[4] = {acc2[hh][0], acc2[hh][1], acc2[hh][2], acc2[hh][3]};
-                    store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(pixel * (unsigned)(F_ * 2) + (unsigned)(kb * 8))), v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dxv[hh][i] = acc2[0][hh][i], dxv[hh][4 + i] = acc2[1][hh][i];
+                if constexpr (ACC) {
+                    const bool has = 8 * kb < p.dx_channels;
+                    const unsigned w[4] = {pre[0][hh].x, pre[0][hh].y, pre[0][hh].z, pre[0][hh].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        dxv[hh][2 * i] += has ? bf_lo(w[i]) : 0.0f, dxv[hh][2 * i + 1] += has ? bf_hi(w[i]) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(dxv[hh][i]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (c_in[hh] && p.dx != nullptr && 8 * kb < p.dx_channels) {
+                    uint4 o;
+                    o.x = pack_bf2(dxv[hh][0], dxv[hh][1]), o.y = pack_bf2(dxv[hh][2], dxv[hh][3]);
+                    o.z = pack_bf2(dxv[hh][4], dxv[hh][5]), o.w = pack_bf2(dxv[hh][6], dxv[hh][7]);
+                    *reinterpret_cast<uint4*>(static_cast<char*>(p.dx) + (size_t)cdx_off[hh]) = o;
+                }
+            }
+            if (want_dh) {
+                const int gy2 = ty0 + dg_row;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int gx2 = tx0 + 16 * hh + l16;
+                    if (c_in[hh]) {
+                        const unsigned pixel = (unsigned)((tb * p.H + gy2) * p.W + gx2);
+                        float v[4] = {acc2[2][hh][0], acc2[2][hh][1], acc2[2][hh][2], acc2[2][hh][3]};
+                        store4(reinterpret_cast<T*>(static_cast<char*>(p.dh_prev) + (size_t)(pixel * (unsigned)(F_ * 2) + (unsigned)(kb * 8))), v);
+                    }
                 }
             }
         }
@@ -801,19 +883,32 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         // 0-3 join after phase B: their interval is [gate backward of tile k + 1, phase B of tile k].  Waves 4-7
         // join between the two, so that phase B of a pass already works on tile k + 1: their interval is [phase B
         // of tile k, gate backward of tile k + 1].  Every wave passes the same number of barriers.
+        // DEFER_LAST: the operands of the last gate-backward pass are requested after phase B instead of inside the
+        // gate backward before it - phase B is where registers are shortest, and that pass still has the passes
+        // before it (and, for waves 0-3, the join) to arrive.  The tile is the one the last gate backward requested.
+        auto request_last_pass = [&](const Tile& r) __attribute__((always_inline)) {
+            if constexpr (K::DEFER_LAST) load_pw(r, std::integral_constant<int, K::NPW - 1>{});
+        };
         flush_hold();
         store_phase(cur, cur_live, nxt);
         __syncthreads();  // (also the weight image)
         if (!m_first) run_b();
+        request_last_pass(nxt);
         for (int k = 0; k < n_iter; ++k) {
             nxt2 = tile_ref(k + 2);
             BSTAMP(s1c);
             gate_backward(nxt, nxt2, lds_dyh + (cur_buf ^ (K::NDY - 1)) * K::DYH_BYTES);
             BSTAMP(s1d);
             BSTAMP_ADD(2, s1c, s1d);  // gate backward of the next tile
-            if (m_first) run_b();
+            if (m_first) {
+                run_b();
+                request_last_pass(nxt2);
+            }
             join();
-            if (!m_first) run_b();
+            if (!m_first) {
+                run_b();
+                request_last_pass(nxt);
+            }
         }
     } else {
         for (int k = 0; k < n_iter; ++k) {

@@ -241,7 +241,9 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   read for them).  dh_above_pool is a power of two.  c_prev and h_prev may both be NULL: the step out of the zero state (nothing is read for
  *   them; the rows of dw_h and of the h part get zero contributions).  dc_prev and dh_prev may both be NULL:
  *   the gradient of the state before this step is not wanted (nothing is written, and where the kernel has a
- *   row tile of its own for dh_prev it is skipped).  Other arguments: as the three calls it replaces. */
+ *   row tile of its own for dh_prev it is skipped).  dx is written in 16-byte pieces: dx_channels and
+ *   dx_channel_stride are multiples of 8 and dx is 16-byte aligned.  Other arguments: as the three calls it
+ *   replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
 int isg_convlstm_bwd_fused(const void* factors, const float* c_prev, const void* h_cur, const void* dh_above,
