@@ -109,6 +109,9 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
     auto stage_load = [&](int k) {
         int b, ty0, tx0;
         if (!tile_origin(k, b, ty0, tx0)) return;
+#ifdef ISG_C32_NO_STAGE
+        if (k > 0) return;
+#endif
 #pragma unroll
         for (int j = 0; j < K::NLOAD; ++j) {
             const int idx = tid + kThreads * j;
@@ -163,17 +166,33 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                 for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
             const char* bb = lds_in + ((2 * wave) * K::HWP + px_l) * K::PSTRIDE + half * 16;
             const char* aw = lds_w + lane * 16;
-#pragma unroll 6
-            for (int s = 0; s < K::NS; ++s) {
+            // Two MFMAs (64 cycles) per k-step against an LDS round trip of 64 - 130: the fragments are requested
+            // AHEAD k-steps before their MFMAs.
+#ifndef ISG_C32_AHEAD
+#define ISG_C32_AHEAD 2
+#endif
+            constexpr int AHEAD = ISG_C32_AHEAD, NB = AHEAD + 1;
+            bf16x8 af[NB], bf[NB][2];
+            auto fetch = [&](int s, int slot) {
                 const int tap = s / K::SPT, q = s % K::SPT;
                 const int ty = tap / KS, tx = tap - ty * KS;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
+                af[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bb + ((ty + pt) * K::HWP + tx) * K::PSTRIDE + q * 32);
-                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[pt], 0, 0, 0);
-                }
+                for (int pt = 0; pt < 2; ++pt)
+                    bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + ((ty + pt) * K::HWP + tx) * K::PSTRIDE + q * 32);
+            };
+#ifndef ISG_C32_NO_KLOOP  // (diagnostic builds leave a part out to see what the others take)
+#pragma unroll
+            for (int s = 0; s < AHEAD; ++s) fetch(s, s);
+#pragma unroll
+            for (int s = 0; s < K::NS; ++s) {
+                if (s + AHEAD < K::NS) fetch(s + AHEAD, (s + AHEAD) % NB);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % NB], bf[s % NB][pt], acc[pt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             // epilogue: lane = pixel; its 16 accumulators are rows 8g + 4 half + i (g = reg >> 2, i = reg & 3).
             // The two halves swap two row groups so that each lane stores whole 16-byte runs of 8 channels.
 #pragma unroll
@@ -368,30 +387,34 @@ __global__ __launch_bounds__(kThreads) void conv32_wgrad_kernel(Conv32WgradParam
         const int q = li >> 2, pp4 = li & 3;
         const int csub = 16 * (g16 & 1) + 4 * pp4;  // channel offset inside the 32 rows
         const int pj = 16 * kh + 8 * half + q;
-#pragma unroll 1
-        for (int r = 0; r < K::TH; ++r) {
-            bf16x8 bfrag;
-            {
-                const char* a0 = lds_dz + (r * TW + pj) * 64 + csub * 2;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
-                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bfrag = __builtin_bit_cast(bf16x8, both);
-            }
+        auto tr_pair = [](const char* a0) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, both);
+        };
+        // (the fragments of the next tile row are requested before this row's MFMAs)
+        const bool last_full = nt == K::TPW;
+        bf16x8 bq[2], aq[2][K::TPW];
+        auto fetch = [&](int r, int slot) {
+            bq[slot] = tr_pair(lds_dz + (r * TW + pj) * 64 + csub * 2);
 #pragma unroll
-            for (int i = 0; i < K::TPW; ++i) {
-                if (i < nt) {
+            for (int i = 0; i < K::TPW; ++i)
+                if (i < K::BASE || last_full) {  // (only the last slot depends on the wave group)
                     const int tap = t0 + i;
                     const int ty = tap / KS, tx = tap - ty * KS;
-                    const char* a0 = lds_in + ((r + ty) * K::HWP + pj + tx) * 64 + csub * 2;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag, acc[i], 0, 0, 0);
+                    aq[slot][i] = tr_pair(lds_in + ((r + ty) * K::HWP + pj + tx) * 64 + csub * 2);
                 }
-            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int r = 0; r < K::TH; ++r) {
+            if (r + 1 < K::TH) fetch(r + 1, (r + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < K::TPW; ++i)
+                if (i < K::BASE || last_full)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[r & 1][i], bq[r & 1], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 

@@ -100,6 +100,14 @@ struct FB {
     // Rows C0 + F .. 63 of the second row tile are padding whose results nobody stores: when they are the tile's
     // upper 16 rows, only its lower 16 are kept in LDS (lanes of the upper rows read the lower rows' fragments).
     static constexpr bool WCOMPACT = MT == 2 && TR == 8 && C0 + F_ <= 48;  // (the wave then owns both row tiles)
+#ifndef ISG_DG_AHEAD
+#define ISG_DG_AHEAD 3
+#endif
+    static constexpr int DG_AHEAD = MT == 1 ? ISG_DG_AHEAD : 1;  // k-steps the data gradient's fragments are requested ahead
+#ifndef ISG_WG_AHEAD
+#define ISG_WG_AHEAD 1
+#endif
+    static constexpr int WG_AHEAD = MT == 1 ? ISG_WG_AHEAD : 1;  // the same for the weight gradient's fragment sets
     static constexpr bool DEFER_LAST = WCOMPACT && PIPE;      // (see request_last_pass in the kernel)
     static constexpr int W1_STEP = WCOMPACT ? 512 : 1024;     // bytes per k-step of the second row tile
     static constexpr int W_BYTES = NS * 1024 + (MT == 2 ? NS * W1_STEP : 0);
@@ -608,7 +616,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             // k-step = 16 consecutive pixels of a tile row.  Both operands come out of pixel-major LDS images
             // through the transposing read; every address is this lane's fixed base plus a compile-time
             // offset, and the fragments of the next k-step are requested before this one's MFMAs.
-            constexpr int NBUF = (MT == 1 || K::HMERGE) ? 2 : 1;  // (the 5-slot kernel has no registers for a second set)
+            // (fragment sets: the 5-slot kernel has registers for one, the others request WG_AHEAD k-steps ahead)
+            constexpr int NBUF = (MT == 1 || K::HMERGE) ? K::WG_AHEAD + 1 : 1;
             bf16x8 bq[NBUF], aq[NBUF][K::NSLOT];
             auto tr_pair = [](const char* a0, auto stride) {  // 8 consecutive pixels of one k-step half
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
@@ -634,12 +643,15 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         }
                     }
             };
-            if constexpr (NBUF == 2) fetch(0, 0);
+            if constexpr (NBUF > 1) {
+#pragma unroll
+                for (int ks = 0; ks < NBUF - 1; ++ks) fetch(ks, ks);
+            }
 #pragma unroll
             for (int ks = 0; ks < 2 * TR; ++ks) {
-                const int cs = NBUF == 2 ? ks & 1 : 0;
-                if constexpr (NBUF == 2) {
-                    if (ks + 1 < 2 * TR) fetch(ks + 1, cs ^ 1);
+                const int cs = ks % NBUF;
+                if constexpr (NBUF > 1) {
+                    if (ks + NBUF - 1 < 2 * TR) fetch(ks + NBUF - 1, (ks + NBUF - 1) % NBUF);
                 } else {
                     fetch(ks, 0);
                 }
@@ -671,17 +683,21 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                                  : K::WCOMPACT ? lds_w + K::NS * 1024 + ((lane >> 5) * 16 + (lane & 15)) * 16
                                                : lds_w + K::NS * 1024 + lane * 16;
                 const int astep = second ? K::W1_STEP : 1024;
-                bf16x8 a[2], b[2];
+                // One MFMA (32 cycles) per k-step against an LDS round trip of 64 - 130: the fragments are requested
+                // DG_AHEAD k-steps ahead, as far as the kernel's registers allow.
+                constexpr int D = K::DG_AHEAD, NB = D + 1;
+                bf16x8 a[NB], b[NB];
                 auto fetch = [&](int s, int slot) {
                     const int tap = s >> 2, qk = s & 3;
                     a[slot] = *reinterpret_cast<const bf16x8*>(aw + s * astep);
                     b[slot] = *reinterpret_cast<const bf16x8*>(bb + ((tap / 3) * HALO_W + (tap % 3)) * K::DY_PSTRIDE + qk * 32);
                 };
-                fetch(0, 0);
+#pragma unroll
+                for (int s = 0; s < D; ++s) fetch(s, s);
 #pragma unroll
                 for (int s = 0; s < K::NS; ++s) {
-                    if (s + 1 < K::NS) fetch(s + 1, (s + 1) & 1);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s & 1], acc, 0, 0, 0);
+                    if (s + D < K::NS) fetch(s + D, (s + D) % NB);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % NB], b[s % NB], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

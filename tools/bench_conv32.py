@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: the square encoder convolutions launched alone at the benchmark shape (B=64, 224 x 224).
+"""Diagnostic: the square encoder convolutions (forward, masked data gradient, weight gradient) launched alone at
+the benchmark shape (B=64, 224 x 224).
 ISG_LIBRARY selects a variant library.  usage: bench_conv32.py [repeats]"""
 import os
 import sys
@@ -30,7 +31,20 @@ def main():
                 ops.conv32(x, w, b, ks, True)
             e1.record()
             torch.cuda.synchronize()
-            out.append("C=%d %dx%d %.4f ms" % (c, ks, ks, e0.elapsed_time(e1) / n))
+            t_fwd = e0.elapsed_time(e1) / n
+            wd = ops.conv32_pack(torch.randn([ks, ks, c, c], device=dev) * 0.05, data_gradient=True)
+            y = torch.relu(torch.randn([64, 224, 224, c], device=dev)).to(torch.bfloat16)
+            times = []
+            for fn in (lambda: ops.conv32_masked(x, wd, y, ks), lambda: ops.conv32_wgrad(x, y, ks)):
+                for _ in range(3):
+                    fn()
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1) / n)
+            out.append("C=%d %dx%d fwd %.4f masked dgrad %.4f wgrad %.4f ms" % (c, ks, ks, t_fwd, times[0], times[1]))
     print(os.environ.get("ISG_LIBRARY", "default"), " | ".join(out))
 
 
