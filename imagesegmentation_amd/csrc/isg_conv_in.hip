@@ -9,6 +9,8 @@
 // Persistent workgroups, weight image resident in LDS, image tile double-buffered through registers.
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "isg_common.h"
 
 namespace {
@@ -117,18 +119,32 @@ __global__ __launch_bounds__(kThreads) void conv_in_fwd_kernel(ConvInParams p) {
                 for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
             const char* bb = buf + ((2 * wave) * K::ROWPX + px_l + 2 * half) * 8;
             const char* aw = lds_w + lane * 16;
-#pragma unroll 4
-            for (int ks = 0; ks < K::NS; ++ks) {
+            // (the fragments are requested two k-steps ahead of their MFMAs)
+#ifndef ISG_CIN_AHEAD
+#define ISG_CIN_AHEAD 2
+#endif
+            constexpr int AHEAD = ISG_CIN_AHEAD, NB = AHEAD + 1;
+            bf16x8 af[NB], bfr[NB][2];
+            auto fetch = [&](int ks, int slot) {
                 const int ky = ks / K::SPK, s = ks - ky * K::SPK;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(aw + ks * 1024);
+                af[slot] = *reinterpret_cast<const bf16x8*>(aw + ks * 1024);
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     const char* src = bb + ((ky + pt) * K::ROWPX + 4 * s) * 8;
                     const uint2 lo = *reinterpret_cast<const uint2*>(src);
                     const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
-                    const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, both), acc[pt], 0, 0, 0);
+                    bfr[slot][pt] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
                 }
+            };
+#pragma unroll
+            for (int ks = 0; ks < AHEAD; ++ks) fetch(ks, ks);
+#pragma unroll
+            for (int ks = 0; ks < K::NS; ++ks) {
+                if (ks + AHEAD < K::NS) fetch(ks + AHEAD, (ks + AHEAD) % NB);
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % NB], bfr[ks % NB][pt], acc[pt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // epilogue: lane = pixel; its 16 accumulators are channels 8g + 4 half + i (g = reg >> 2, i = reg & 3).
             // The two halves swap two channel groups so that each lane stores whole 16-byte runs of 8 channels.
@@ -292,30 +308,37 @@ __global__ __launch_bounds__(kWgThreads) void conv_in_wgrad_kernel(ConvInWgradPa
         const int q = li >> 2, pp4 = li & 3;
         const int csub = 16 * (g16 & 1) + 4 * pp4;  // (virtual) channel offset inside a 32-row tile
         const int pj = 16 * kh + 8 * half + q;
-#pragma unroll 1
-        for (int r = 0; r < TH; ++r) {
-            bf16x8 bfrag;
-            {
-                const char* a0 = lds_dz + (r * TW + pj) * 64 + csub * 2;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 64));
-                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bfrag = __builtin_bit_cast(bf16x8, both);
-            }
+        auto tr_pair = [](const char* a0, auto second) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(a0 + decltype(second)::value));
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, both);
+        };
+        // (the fragments of the next tile row are requested before this row's MFMAs; with 28 tiles every wave
+        // group has all its slots in use and nothing in the loop is conditional)
+        constexpr bool kAllFull = K::NT == 4 * K::TPW;
+        bf16x8 bq[2], aq[2][K::TPW];
+        auto fetch = [&](int r, int slot) {
+            bq[slot] = tr_pair(lds_dz + (r * TW + pj) * 64 + csub * 2, std::integral_constant<int, 4 * 64>{});
 #pragma unroll
-            for (int i = 0; i < K::TPW; ++i) {
-                if (i < nt) {
+            for (int i = 0; i < K::TPW; ++i)
+                if (kAllFull || i < nt) {
                     const int t = t0 + i;
                     const int ky = t / K::MTW, mt = t % K::MTW;
-                    const char* a0 = lds_in + ((r + ky) * F::ROWPX + pj) * 8 + (32 * mt + csub) * 2;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * 8));
-                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), bfrag, acc[i], 0, 0, 0);
+                    aq[slot][i] = tr_pair(lds_in + ((r + ky) * F::ROWPX + pj) * 8 + (32 * mt + csub) * 2,
+                                          std::integral_constant<int, 4 * 8>{});
                 }
-            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+            if (r + 1 < TH) fetch(r + 1, (r + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < K::TPW; ++i)
+                if (kAllFull || i < nt)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[r & 1][i], bq[r & 1], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 

@@ -45,6 +45,25 @@ def main():
                 torch.cuda.synchronize()
                 times.append(e0.elapsed_time(e1) / n)
             out.append("C=%d %dx%d fwd %.4f masked dgrad %.4f wgrad %.4f ms" % (c, ks, ks, t_fwd, times[0], times[1]))
+    # the first layer: 3 -> 32 channels, 14 x 14 taps
+    img = torch.randn([64, 224, 224, 3], device=dev).to(torch.bfloat16)
+    x4 = ops.conv_in_pad_image(img)
+    w1 = torch.randn([14, 14, 3, 32], device=dev) * 0.05
+    wimg = ops.conv_in_pack(w1)
+    b1 = torch.zeros([32], device=dev)
+    dz = torch.randn([64, 224, 224, 32], device=dev).to(torch.bfloat16)
+    times = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for fn in (lambda: ops.conv_in_fwd(x4, wimg, b1, 14, relu=True), lambda: ops.conv_in_wgrad(x4, dz, 14)):
+        for _ in range(3):
+            fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / n)
+    out.append("first layer 14x14 fwd %.4f wgrad %.4f ms" % tuple(times))
     print(os.environ.get("ISG_LIBRARY", "default"), " | ".join(out))
 
 
