@@ -233,3 +233,61 @@ int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int 
     return isg::check_launch("bias_partial_reduce_kernel");
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Weight images of the encoder convolutions from HWIO float weights: one launch per image (the weights change every
+// training step).  One thread per element of the image.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// [KS*KS*C/16][64][8]: element [tap * (C/16) + q][32 kg + m][j] = A[tap][m][16 q + 8 kg + j]; forward
+// A[tap][m][k] = w[ty][tx][k][m], data gradient A[tap][m][k] = w[KS-1-ty][KS-1-tx][m][k]; rows m >= C are zero.
+__global__ __launch_bounds__(256) void conv_square_pack_kernel(const float* __restrict__ w, int KS, int C, int data_gradient,
+                                                               __bf16* __restrict__ out, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
+    const int spt = C / 16;
+    const int tap = s / spt, q = s - tap * spt;
+    const int m = lane & 31, k = 16 * q + 8 * (lane >> 5) + j;
+    const int ty = tap / KS, tx = tap - ty * KS;
+    float v = 0.0f;
+    if (m < C)
+        v = data_gradient ? w[(((KS - 1 - ty) * KS + (KS - 1 - tx)) * C + m) * C + k] : w[((ty * KS + tx) * C + k) * C + m];
+    out[idx] = (__bf16)v;
+}
+
+// [KS * KXP/4][64][8], KXP = KS rounded up to 4: element [ky * KXP/4 + s][32 kg + m][j] =
+// w[ky][4 s + 2 kg + j / 4][j % 4][m], 0 where kx >= KS, the channel is 3 or m >= cout.
+__global__ __launch_bounds__(256) void conv_in_pack_kernel(const float* __restrict__ w, int KS, int cout,
+                                                           __bf16* __restrict__ out, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63, r = idx >> 9;
+    const int spk = ((KS + 3) / 4 * 4) / 4;
+    const int ky = r / spk, s = r - ky * spk;
+    const int m = lane & 31, kx = 4 * s + 2 * (lane >> 5) + (j >> 2), c = j & 3;
+    float v = 0.0f;
+    if (kx < KS && c < 3 && m < cout) v = w[((ky * KS + kx) * 3 + c) * cout + m];
+    out[idx] = (__bf16)v;
+}
+
+}  // namespace
+
+extern "C" int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg, void* stream) {
+    ISG_REQUIRE(w && wimg, ISG_EINVAL, "isg_conv32_pack: null argument");
+    ISG_REQUIRE((KS == 3 || KS == 5) && (C == 16 || C == 32), ISG_EINVAL, "isg_conv32_pack: 3 x 3 or 5 x 5 taps, 16 or 32 channels");
+    const int total = KS * KS * (C / 16) * 512;
+    hipLaunchKernelGGL(conv_square_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, KS,
+                       C, data_gradient, static_cast<__bf16*>(wimg), total);
+    return isg::check_launch("conv_square_pack_kernel");
+}
+
+extern "C" int isg_conv_in_pack(const float* w, int KS, int cout, void* wimg, void* stream) {
+    ISG_REQUIRE(w && wimg, ISG_EINVAL, "isg_conv_in_pack: null argument");
+    ISG_REQUIRE((KS == 14 || KS == 5) && (cout == 16 || cout == 32), ISG_EINVAL, "isg_conv_in_pack: 14 x 14 or 5 x 5 taps, 16 or 32 output channels");
+    const int total = KS * (((KS + 3) / 4 * 4) / 4) * 512;
+    hipLaunchKernelGGL(conv_in_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, KS,
+                       cout, static_cast<__bf16*>(wimg), total);
+    return isg::check_launch("conv_in_pack_kernel");
+}

@@ -425,9 +425,11 @@ def conv_in_pack(w_hwio):
     rows padded to the 32 of an MFMA tile)."""
     ks, cout = w_hwio.shape[0], w_hwio.shape[3]
     kxp = (ks + 3) // 4 * 4
-    w = torch.nn.functional.pad(w_hwio.detach().float(), (0, 32 - cout, 0, 1, 0, kxp - ks))  # [KS, KXP, 4, 32]
-    w = w.reshape(ks, kxp // 4, 2, 2, 4, 32).permute(0, 1, 2, 5, 3, 4)                        # [ky, s, kg, m, jx, c]
-    return w.reshape(ks * (kxp // 4), 64, 8).to(torch.bfloat16).contiguous()
+    w = w_hwio.detach().float().contiguous()
+    out = torch.empty([ks * (kxp // 4), 64, 8], dtype=torch.bfloat16, device=w.device)
+    rc = _lib.lib().isg_conv_in_pack(_lib.ptr(w), int(ks), int(cout), _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_conv_in_pack")
+    return out
 
 
 def conv_in_pad_image(x3):
@@ -482,13 +484,13 @@ def conv32_pack(w_hwio, data_gradient=False):
     """HWIO float weights [KS,KS,C,C] (C = 32 or 16) -> the kernel's bf16 A-fragment image [KS*KS*C/16, 64, 8]
     (output-channel rows padded to the 32 of an MFMA tile); with ``data_gradient`` the image of the transposed
     convolution (flipped taps, channels swapped)."""
-    w = w_hwio.detach().float()
-    if data_gradient:
-        w = w.flip(0, 1).permute(0, 1, 3, 2)
+    w = w_hwio.detach().float().contiguous()
     ks, c = w.shape[0], w.shape[2]
-    w = torch.nn.functional.pad(w, (0, 32 - c))                         # [ks, ks, cin, 32 rows]
-    w = w.reshape(ks * ks, c // 16, 2, 8, 32).permute(0, 1, 2, 4, 3)    # [tap, q, kg, m, j]
-    return w.reshape(ks * ks * (c // 16), 64, 8).to(torch.bfloat16).contiguous()
+    out = torch.empty([ks * ks * (c // 16), 64, 8], dtype=torch.bfloat16, device=w.device)
+    rc = _lib.lib().isg_conv32_pack(_lib.ptr(w), int(ks), int(c), int(bool(data_gradient)), _lib.ptr(out),
+                                    _lib.current_stream())
+    _lib.check(rc, "isg_conv32_pack")
+    return out
 
 
 def conv32(x, wimg, bias, ks, relu):

@@ -362,11 +362,13 @@ int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, 
  *   wimg: bf16 [KS * KXP/4][64][8] with KXP = KS rounded up to 4; element [ky * KXP/4 + s][32 kg + m][j] =
  *         w[ky][4 s + 2 kg + j / 4][j % 4][m] (HWIO), 0 where kx >= KS, the channel is 3 or m >= cout;
  *         isg_conv_in_packed_elems(KS, cout) gives its length (-1: no such instantiation).
+ *   isg_conv_in_pack:  that image from float HWIO weights w [KS][KS][3][cout], one launch.
  *   isg_conv_in_fwd:   y bf16 [B][H][W][cout] = act(conv(x4, w) + bias), act = ReLU when relu != 0.
  *   isg_conv_in_wgrad: dw float [KS][KS][3][cout] (overwritten) = gradient of the convolution for
  *         dz bf16 [B][H][W][cout] (the gradient after the ReLU mask, see isg_relu_bwd_bias); workspace:
  *         device scratch of isg_conv_in_wgrad_workspace_bytes(KS, cout) bytes. */
 long long isg_conv_in_packed_elems(int KS, int cout);
+int isg_conv_in_pack(const float* w, int KS, int cout, void* wimg, void* stream);
 int isg_conv_in_pad_image(const void* x3, long long npix, void* x4, void* stream);
 int isg_conv_in_fwd(const void* x4, const void* wimg, const float* bias, int B, int H, int W, int KS, int cout, int relu,
                     void* y, void* stream);
@@ -384,6 +386,9 @@ int isg_conv_in_wgrad(const void* x4, const void* dz, int B, int H, int W, int K
  *   isg_conv32_wgrad: dw float [KS][KS][32][32] (HWIO, overwritten) for input x and output gradient dz
  *       (after the ReLU mask); workspace of isg_conv32_wgrad_workspace_bytes(KS) bytes. */
 long long isg_conv32_packed_elems(int KS);
+/* The image of isg_conv32 / isg_conv16 (C = 32 / 16: [KS*KS*C/16][64][8], element [tap * C/16 + q][32 kg + m][j], rows
+ * m >= C zero) from float HWIO weights w [KS][KS][C][C], forward or (data_gradient != 0) data gradient; one launch. */
+int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg, void* stream);
 int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
                void* stream);
 long long isg_conv32_wgrad_workspace_bytes(int KS);

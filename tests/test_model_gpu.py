@@ -599,3 +599,29 @@ def test_training_from_the_device_batch_builder_equals_host_batches():
             loss = model.train_step(images, d, pts, tg)
         losses.append((loss.item(), model.dense_bias.detach().clone()))
     assert losses[0][0] == losses[1][0] and torch.equal(losses[0][1], losses[1][1])
+
+
+@pytest.mark.gpu
+def test_encoder_weight_images_match_their_documented_layouts():
+    """isg_conv32_pack / isg_conv_in_pack (one launch per image) against the element formulas of include/isg.h
+    written out with torch: forward and data-gradient images of the square layers (3 x 3 and 5 x 5, 16 and 32
+    channels), the first layer's image (14 x 14 -> 32, 5 x 5 -> 16).  Bit-exact: a layout, and one rounding to bf16."""
+    from imagesegmentation_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(5)
+    for ks in (3, 5):
+        for c in (16, 32):
+            w = torch.randn([ks, ks, c, c], device=d, generator=g)
+            for dgrad in (False, True):
+                a = w.flip(0, 1).permute(0, 1, 3, 2) if dgrad else w          # A[ty][tx][k][m]
+                a = torch.nn.functional.pad(a, (0, 32 - c))
+                want = a.reshape(ks * ks, c // 16, 2, 8, 32).permute(0, 1, 2, 4, 3).reshape(ks * ks * (c // 16), 64, 8)
+                got = ops.conv32_pack(w, data_gradient=dgrad)
+                assert got.dtype == torch.bfloat16 and torch.equal(got, want.to(torch.bfloat16)), (ks, c, dgrad)
+    for ks, cout in ((14, 32), (5, 16), (14, 16), (5, 32)):
+        w = torch.randn([ks, ks, 3, cout], device=d, generator=g)
+        kxp = (ks + 3) // 4 * 4
+        a = torch.nn.functional.pad(w, (0, 32 - cout, 0, 1, 0, kxp - ks))      # [ky][kx][4][32]
+        want = a.reshape(ks, kxp // 4, 2, 2, 4, 32).permute(0, 1, 2, 5, 3, 4).reshape(ks * (kxp // 4), 64, 8)
+        got = ops.conv_in_pack(w)
+        assert torch.equal(got, want.to(torch.bfloat16)), (ks, cout)
