@@ -73,6 +73,8 @@ SIGNATURES = {
                                   _vp, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_bwd_fused_supported": (_int, [_int, _int, _int, _int, _int, _int, _int]),
     "isg_convlstm_bwd_fused_hist_bytes": (_ll, [_int, _int]),
+    "isg_convlstm_bwd_fused_hist_begin": (_int, [_vp, _int, _int, _vp]),
+    "isg_convlstm_bwd_fused_hist_finish": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),
     "isg_convlstm_bwd_fused": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                       _int, _int, _vp, _int, _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
                                       _int, _vp, _vp]),

@@ -531,6 +531,9 @@ class _SequenceFunction(torch.autograd.Function):
         # gradients of neighbouring tiles' border pixels, so they alternate between two buffers per layer.
         dc_next = [torch.empty_like(dc_state[l]) if fused[l] else None for l in range(L)]
         dh_next = [torch.empty_like(dh_state[l]) if fused[l] else None for l in range(L)]
+        # history taps of a fused layer: their dY rows are kept per step and folded into dw_x once after the sweep
+        hist_scratch = [ops.bwd_fused_hist_begin(B, t_run, packed[l], dev) if fused[l] and packed[l].hist and t_run > 0
+                        else None for l in range(L)]
         for t in reversed(range(t_run)):
             x0 = seq.get(t)
             for l in reversed(range(L)):
@@ -559,7 +562,8 @@ class _SequenceFunction(torch.autograd.Function):
                                   None if last else dh_state[l], None if last else dc_state[l], x_in,
                                   None if first else Hs[l][t], packed[l],
                                   None if first else dc_next[l], None if first else dh_next[l], slabs[l], mode,
-                                  grads[l][0], durations=durations_dev, t=t, hist_points=pts, pool=k, **dx_args)
+                                  grads[l][0], durations=durations_dev, t=t, hist_points=pts, pool=k,
+                                  hist_slot=(hist_scratch[l], t) if hist_scratch[l] is not None else None, **dx_args)
                     dc_state[l], dc_next[l] = dc_next[l], dc_state[l]
                     dh_state[l], dh_next[l] = dh_next[l], dh_state[l]
                     continue
@@ -571,6 +575,8 @@ class _SequenceFunction(torch.autograd.Function):
         if t_run > 0:
             for l in range(L):
                 ops.wgrad_finish(slabs[l], (B, H, W, packed[l].cs), packed[l].c, packed[l].hist, *grads[l])
+                if hist_scratch[l] is not None:
+                    ops.bwd_fused_hist_finish(hist_scratch[l], B, t_run, packed[l], grads[l][0])
         if seq.x_seq is not None:
             d_input = d_in[..., :seq.C].to(ctx.in_dtype)
         else:

@@ -1113,6 +1113,9 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
                                       void* hist_scratch, void* dc_prev, void* dh_prev, void* dx, int dx_channels,
                                       int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
                                       void* stream) {
+    // (ISG_HIST_DEFER: the caller zeroes the history scratch once and folds it once, see isg_convlstm_bwd_fused_hist_finish)
+    const bool hist_defer = (mode & ISG_HIST_DEFER) != 0;
+    mode &= ~ISG_HIST_DEFER;
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
@@ -1154,7 +1157,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     p.bias_slab = p.slab + (size_t)kWgradMaxBlocks * 9 * MT * 32 * NG;
     p.slab_accumulate = mode == ISG_WGRAD_DEFER;
     p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_dy = hist_scratch;
-    if (hist > 0) {
+    if (hist > 0 && !hist_defer) {
         hipError_t e = hipMemsetAsync(hist_scratch, 0, (size_t)hist_dy_bytes(B, hist), s);
         ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
@@ -1174,7 +1177,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
 #endif
 #endif
     if (rc != ISG_OK) return rc;
-    if (hist > 0) {
+    if (hist > 0 && !hist_defer) {
         float* partial = reinterpret_cast<float*>(static_cast<char*>(hist_scratch) + hist_dy_bytes(B, hist));
         hipLaunchKernelGGL(hist_side_partial_kernel, dim3(9 * hist, kHistGroups), dim3(256), 0, s,
                            static_cast<const __bf16*>(hist_scratch), B, hist, partial);
@@ -1185,4 +1188,25 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
         rc = isg::check_launch("hist_side_finish_kernel");
     }
     return rc;
+}
+
+extern "C" int isg_convlstm_bwd_fused_hist_begin(void* hist_scratch, int samples, int hist, void* stream) {
+    ISG_REQUIRE(hist_scratch && samples > 0 && hist > 0 && hist <= 2, ISG_EINVAL, "isg_convlstm_bwd_fused_hist_begin: bad argument");
+    hipError_t e = hipMemsetAsync(hist_scratch, 0, (size_t)hist_dy_bytes(samples, hist), static_cast<hipStream_t>(stream));
+    ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return ISG_OK;
+}
+
+extern "C" int isg_convlstm_bwd_fused_hist_finish(void* hist_scratch, int samples, int hist, int C, int accumulate,
+                                                  float* dw_x, void* stream) {
+    ISG_REQUIRE(hist_scratch && dw_x && samples > 0 && hist > 0 && hist <= 2 && C > 0, ISG_EINVAL,
+                "isg_convlstm_bwd_fused_hist_finish: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(hist_scratch) + hist_dy_bytes(samples, hist));
+    hipLaunchKernelGGL(hist_side_partial_kernel, dim3(9 * hist, kHistGroups), dim3(256), 0, s,
+                       static_cast<const __bf16*>(hist_scratch), samples, hist, partial);
+    int rc = isg::check_launch("hist_side_partial_kernel");
+    if (rc != ISG_OK) return rc;
+    hipLaunchKernelGGL(hist_side_finish_kernel, dim3(9 * hist), dim3(NG), 0, s, partial, hist, C, accumulate ? 1 : 0, dw_x);
+    return isg::check_launch("hist_side_finish_kernel");
 }

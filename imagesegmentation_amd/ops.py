@@ -332,16 +332,36 @@ def bwd_fused_supported(packed, B, H, W):
 
 
 _hist_scratch = {}
+HIST_DEFER = 0x100
+
+
+def bwd_fused_hist_begin(B, steps, packed, device):
+    """Zeroed scratch for the history taps' dY of ``steps`` fused backward steps (one slot per step), folded into
+    ``dw_x`` once by ``bwd_fused_hist_finish`` instead of after every step."""
+    n = _lib.lib().isg_convlstm_bwd_fused_hist_bytes(B * steps, packed.hist)
+    scratch = torch.empty([n // 2], dtype=torch.bfloat16, device=device)
+    rc = _lib.lib().isg_convlstm_bwd_fused_hist_begin(_lib.ptr(scratch), B * steps, packed.hist, _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_bwd_fused_hist_begin")
+    return scratch
+
+
+def bwd_fused_hist_finish(scratch, B, steps, packed, dw_x, accumulate=False):
+    rc = _lib.lib().isg_convlstm_bwd_fused_hist_finish(_lib.ptr(scratch), B * steps, packed.hist, packed.c,
+                                                       int(bool(accumulate)), _lib.ptr(dw_x), _lib.current_stream())
+    _lib.check(rc, "isg_convlstm_bwd_fused_hist_finish")
+
 
 
 @_timed("bwd_fused")
 def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
               dh_prev, workspace, mode, dw_x, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0,
-              hist_points=None, pool=1):
+              hist_points=None, pool=1, hist_slot=None):
     """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward from the ``factors``
     the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), the cell state before the step (``c_prev``)
     and the step's new h (``h_cur``); data gradient (dx optional, dh_prev) and
     weight gradient (deferred partial sums in ``workspace``; the history taps' rows of ``dw_x`` directly).
+    ``hist_slot`` = (scratch, step): the history taps' dY goes to slot ``step`` of a sequence's scratch
+    (``bwd_fused_hist_begin``) and ``dw_x`` is left to ``bwd_fused_hist_finish``.
     dc_state / dh_state are read, dc_prev / dh_prev written: different buffers.  c_prev = h_prev = None: the step
     out of the zero state; dc_prev = dh_prev = None: the gradient of the state before the step is not wanted."""
     B, H, W, F = h_cur.shape
@@ -350,7 +370,11 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
     assert (c_prev is None or c_prev.dtype == torch.float32) and h_cur.dtype == torch.bfloat16
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     scratch = None
-    if packed.hist:
+    scratch_ptr = None
+    if packed.hist and hist_slot is not None:
+        scratch_ptr = hist_slot[0].data_ptr() + int(hist_slot[1]) * B * packed.hist * 9 * 64 * 2
+        mode = int(mode) | HIST_DEFER
+    elif packed.hist:
         key = (B, packed.hist, str(gates.device))
         scratch = _hist_scratch.get(key)
         if scratch is None:
@@ -360,7 +384,8 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
         _lib.ptr(gates), _lib.ptr(c_prev), _lib.ptr(h_cur), dh_above.data_ptr() if dh_above is not None else None,
         int(dh_above_batch_stride), int(pool), _lib.ptr(dh_state), _lib.ptr(dc_state), _lib.ptr(x), _lib.ptr(h_prev),
         _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype), _lib.ptr(durations), int(t),
-        pts, packed.hist, pts_stride, _lib.ptr(scratch), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx),
+        pts, packed.hist, pts_stride, scratch_ptr if scratch_ptr is not None else _lib.ptr(scratch), _lib.ptr(dc_prev),
+        _lib.ptr(dh_prev), _lib.ptr(dx),
         int(dx_channels), int(dx.shape[-1]) if dx is not None else 0, int(bool(dx_accumulate)), _lib.ptr(workspace),
         int(mode), _lib.ptr(dw_x), _lib.current_stream())
     _lib.check(rc, "isg_convlstm_bwd_fused")

@@ -235,7 +235,12 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   workspace / mode: as isg_convlstm_wgrad with ISG_WGRAD_DEFER_FIRST (overwrite) or ISG_WGRAD_DEFER (add);
  *   close the sequence with isg_convlstm_wgrad_finish.  With hist > 0 the gradient of the history taps goes
  *   to the hist channels of dw_x (assigned / added by the same mode) through hist_scratch, device scratch of
- *   isg_convlstm_bwd_fused_hist_bytes(B, hist) bytes.
+ *   isg_convlstm_bwd_fused_hist_bytes(B, hist) bytes.  Over a sequence the zero fill and the fold of that
+ *   scratch can be done once instead of per step: scratch of isg_convlstm_bwd_fused_hist_bytes(B * T, hist)
+ *   bytes, isg_convlstm_bwd_fused_hist_begin(scratch, B * T, hist) before the first step, every step with
+ *   mode | ISG_HIST_DEFER and hist_scratch = scratch + t * B * hist * 9 * 64 * 2 bytes (a slot of its own per
+ *   step; dw_x is then not touched by the step), and isg_convlstm_bwd_fused_hist_finish(scratch, B * T, hist, C,
+ *   accumulate, dw_x) after the last one (assigns the hist channels of dw_x, or adds to them).
  *   dh_above must be given (zeros where there is no gradient); dh_state and dc_state may both be NULL: no
  *   gradient is carried in (the last step of a sequence whose final state is not differentiated; nothing is
  *   read for them).  dh_above_pool is a power of two.  c_prev and h_prev may both be NULL: the step out of the zero state (nothing is read for
@@ -246,6 +251,10 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
+enum { ISG_HIST_DEFER = 0x100 };
+int isg_convlstm_bwd_fused_hist_begin(void* hist_scratch, int samples, int hist, void* stream);
+int isg_convlstm_bwd_fused_hist_finish(void* hist_scratch, int samples, int hist, int C, int accumulate, float* dw_x,
+                                       void* stream);
 int isg_convlstm_bwd_fused(const void* factors, const float* c_prev, const void* h_cur, const void* dh_above,
                            long long dh_above_batch_stride, int dh_above_pool, const void* dh_state, const void* dc_state, const void* x,
                            const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs, int F,
