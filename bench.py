@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the two hot paths on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config rnnconv|endtokendeep2] [--scaling weak|strong]
 
 Headline (the JSON line's metric/value): polygon sequences per second, forward + backward + optimiser,
 of the RNNConvExperiment graph (encoder 32@14,32@5,32@3 -> 2 x ConvLSTM(16) -> head) on 224 x 224
 synthetic polygons, batch 64 per GPU, teacher forced, T = 5.  The
 reference's dense head (P*P*16 -> P*P) has 4e10 weights at P = 224 and cannot exist; as the reference
 never runs above 28 x 28, the head here average-pools the recurrent output 8x to the 28 x 28 grid the
-reference's head was built for (Model(head_size=28)).
+reference's head was built for (Model(head_size=28)).  ``--config endtokendeep2`` times the
+EndTokenDeepExperiment_2 graph (7 encoder layers, 5 x ConvLSTM(16), T = 10, P*P+1 classes, 32 sequences per GPU,
+28 x 28 unless --size says otherwise) in the same line shape.
 
 Also reported in the same line: IoU rollouts per second of the rasteriser (16,384 rollouts at 224 x 224,
 masks materialised), per-kernel rooflines measured with events on the launch stream, and CPU baselines
@@ -17,7 +19,13 @@ timed on the host cores in the same run (rank 0, N = 1 only).
 One process per GPU (RCCL all-reduce of the flat gradient bucket per step; the rasteriser shards rollouts
 with no collective).  `python bench.py --gpus N` with N > 1 starts its own N ranks through
 torch.distributed.run before anything touches a GPU and exits with their status; started under a launcher
-already (WORLD_SIZE set) it is one of the ranks.
+already (WORLD_SIZE set) it is one of the ranks.  ``--scaling weak`` (default) keeps the per-GPU work fixed,
+``--scaling strong`` keeps the global batch / rollout counts fixed and splits them over the ranks.
+
+Every rank walks ONE control flow (``run_legs``); whatever issues a collective (a training step, an RL update, a
+fence, a timing reduction) runs on every rank or on none.  ``--launch-check`` walks the same function with
+stand-in legs that do no GPU work but issue the same collectives through the same ``parallel`` helpers on gloo
+host tensors, and checks before each collective that all ranks are about to issue the same one.
 """
 import argparse
 import ctypes
@@ -36,14 +44,25 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 HBM_PEAK_GBS = 8000.0
 
 
+CONFIGS = {
+    # name -> (experiment graph, default size, default sequences per GPU)
+    "rnnconv": ("RNNConv", 224, 64),              # reference polyrnn/RNNConvExperiment.py
+    "endtokendeep2": ("EndTokenDeep_2", 28, 32),  # reference polyrnn/EndTokenDeepExperiment_2.py:19-57,202-205,224-226
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--config", default="rnnconv", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch / --rollouts / --rl-envs / --a3c-envs are per GPU; strong: they are the "
+                         "whole job's and are split over the ranks")
+    ap.add_argument("--size", type=int, default=None, help="image side (default: the config's)")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default: the config's)")
     ap.add_argument("--rollouts", type=int, default=16384, help="IoU rollouts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -55,17 +74,21 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=0.0,
                     help="idle pause before the warm-up (diagnostic; see main)")
     ap.add_argument("--launch-check", action="store_true",
-                    help="no GPU work: every rank joins the process group (ISG_DIST_BACKEND, default nccl), runs the "
-                         "timed region's fences and reductions around an empty step on host tensors, and rank 0 prints "
-                         "a JSON line - checks the multi-rank launch path on a machine without GPUs")
+                    help="no GPU work: every rank joins the process group (ISG_DIST_BACKEND, default gloo) and walks "
+                         "the whole control flow of a run with stand-in legs that issue the real collectives on host "
+                         "tensors; rank 0 prints a JSON line - checks the multi-rank path on a machine without GPUs")
     ap.add_argument("--no-extra-runs", action="store_true",
-                    help="skip the two extra training legs (every sequence at full length; the same step in f32)")
+                    help="skip the extra legs (full-length sequences, f32, fresh batches, the other config, decode)")
     ap.add_argument("--kernels-only", action="store_true",
                     help="launch each hot kernel 3 times and exit (the run the PMC counter passes profile)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    _, size, batch = CONFIGS[args.config]
+    args.size = size if args.size is None else args.size
+    args.batch = batch if args.batch is None else args.batch
+    return args
 
 
-def make_batch(size, batch, T, hist, head_size, seed, device, dtype):
+def make_batch(size, batch, T, hist, head_size, seed, device, dtype, end_token=False):
     """Synthetic polygons by the reference generator recipe, rasterised by the HIP rasteriser, laid out
     as the reference's teacher-forcing batch (history as vertex points, targets on the head grid)."""
     from imagesegmentation_amd import data, util
@@ -78,7 +101,8 @@ def make_batch(size, batch, T, hist, head_size, seed, device, dtype):
             cache[key] = util.create_shape_mask(verts, s)
         return cache[key]
 
-    ds = data.PolygonDataset.synthetic(batch, size, size, T, hist, seed=seed, shape_mask_fn=mask_fn)
+    ds = data.PolygonDataset.synthetic(batch, size, size, T, hist, seed=seed, shape_mask_fn=mask_fn,
+                                       end_token=end_token)
     np.random.seed(seed + 1)
     d, images, pts, targets, verts = ds.get_batch_points(batch)
     d = np.minimum(d, T).astype(np.int32)
@@ -86,7 +110,7 @@ def make_batch(size, batch, T, hist, head_size, seed, device, dtype):
     targets = targets // scale
     return dict(durations=d, images=torch.as_tensor(images, device=device).to(dtype).contiguous(),
                 points=torch.as_tensor(pts, device=device), targets=torch.as_tensor(targets, device=device),
-                vertices=verts, images_np=images, points_np=pts, targets_np=targets)
+                vertices=verts, images_np=images, points_np=pts, targets_np=targets, dataset=ds)
 
 
 def event_time_ms(fn, reps):
@@ -111,7 +135,10 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
     B, P = batch["images"].shape[0], model.prediction_size
     F = 16
     out = []
+    n_layers = len(model.rnn.cells)
     for l, cell in enumerate(model.rnn.cells):
+        if l not in (0, 1, n_layers - 1):
+            continue  # layers 1 .. L-2 are the same launch
         hist = model.history_length if l == 0 else 0  # layer 0 takes its history frames as points
         packed = cell.packed(hist=hist)
         cs, c_real = packed.cs, cell.input_to_state_kernel.shape[2]
@@ -401,36 +428,496 @@ def self_launch(n):
     return subprocess.call(cmd)
 
 
-def launch_check(args, world, rank):
-    """The collectives of the timed region (barrier fences, MAX over ranks of the elapsed time, SUM of a per-rank
-    rate) on host tensors, no GPU: what --launch-check runs."""
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("ISG_DIST_BACKEND", "gloo"))
-    if os.environ.get("ISG_BENCH_FAIL_RANK") == str(rank):
-        raise SystemExit("rank %d asked to fail (ISG_BENCH_FAIL_RANK)" % rank)
-    if world > 1:
-        dist.barrier()
+class Comm:
+    """The bench's own collectives (fences and reductions of timings), on device tensors in a real run and on host
+    tensors under --launch-check.  With one rank nothing is issued."""
+
+    def __init__(self, world, device, sync):
+        self.world, self.device, self.sync = world, device, sync
+
+    def fence(self):
+        self.sync()
+        if self.world > 1:
+            torch.distributed.barrier()
+        self.sync()
+
+    def _reduce(self, value, op):
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([value], device=self.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max(self, value):
+        return self._reduce(value, torch.distributed.ReduceOp.MAX)
+
+    def sum(self, value):
+        return self._reduce(value, torch.distributed.ReduceOp.SUM)
+
+
+def per_rank(args, world):
+    """Work of one rank: the arguments themselves under weak scaling, their share under strong scaling."""
+    n = world if args.scaling == "strong" else 1
+    for name in ("batch", "rollouts", "rl_envs", "a3c_envs"):
+        if getattr(args, name) % n != 0:
+            raise SystemExit("--scaling strong: --%s %d does not divide over %d ranks" %
+                             (name.replace("_", "-"), getattr(args, name), world))
+    return dict(batch=args.batch // n, rollouts=args.rollouts // n, rl_envs=args.rl_envs // n,
+                a3c_envs=args.a3c_envs // n)
+
+
+class GpuWorkload:
+    """The legs of a real run on this rank's GPU.  Methods that issue collectives say so; ``run_legs`` calls those on
+    every rank."""
+
+    def __init__(self, args, world, rank, local_rank):
+        self.args, self.world, self.rank = args, world, rank
+        # rehearsal on a box with fewer GPUs than ranks: ISG_DIST_BACKEND=gloo lets several ranks share a device
+        backend = os.environ.get("ISG_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        if not args.no_miopen_find:
+            torch.backends.cudnn.benchmark = True
+        self.device = device = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=device)
+            else:
+                torch.distributed.init_process_group(backend)
+        self.comm = Comm(world, device, torch.cuda.synchronize)
+        self.share = per_rank(args, world)
+        self.dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        self.size = args.size
+        self.head_size = 28 if args.size % 28 == 0 else args.size
+        self.model, self.batch = self._make(CONFIGS[args.config][0], self.size, self.share["batch"], self.dtype, seed=rank)
+        self.T, self.hist = self.model.max_timesteps, self.model.history_length
+
+    def _make(self, graph, size, batch, dtype, seed):
+        from imagesegmentation_amd.polyrnn import experiments
+        head_size = 28 if size % 28 == 0 else size
+        model = experiments.make(graph, image_size=size, compute_dtype=dtype, device=self.device, seed=0,
+                                 head_size=head_size)
+        bt = make_batch(size, batch, model.max_timesteps, model.history_length, head_size, seed=seed,
+                        device=self.device, dtype=dtype, end_token=model.end_token)
+        return model, bt
+
+    def close(self):
+        if self.world > 1:
+            torch.distributed.destroy_process_group()
+
+    # -- the training step (collectives: the early tail all-reduce from the autograd hook + the remainder) ----
+    def train_step(self, model=None, batch=None, durations=None):
+        m = self.model if model is None else model
+        b = self.batch if batch is None else batch
+        return m.train_step(b["images"], b["durations"] if durations is None else durations, b["points"], b["targets"])
+
+    def describe(self):
+        m = self.model
+        return {"workload": "polyrnn %sExperiment graph, teacher-forced training step (fwd+bwd+clip+Adam), %dx%d "
+                            "synthetic polygons, batch %d per GPU, T=%d, %dxConvLSTM(16), dense head on the %dx%d grid%s" %
+                            (CONFIGS[self.args.config][0], self.size, self.size, self.share["batch"], self.T,
+                             len(m.rnn.cells), self.head_size, self.head_size,
+                             " (8x-pooled)" if self.head_size != self.size else ""),
+                "mean_duration": float(np.mean(self.batch["durations"]))}
+
+    def allreduce_bytes(self):
+        return int(self.model._flat_grad.numel() * 4)
+
+    def conv_flops_per_sequence(self, model=None, durations=None):
+        m = self.model if model is None else model
+        d = self.batch["durations"] if durations is None else durations
+        return 3.0 * sum(2.0 * self.size * self.size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
+                         for c in m.rnn.cells) * float(np.mean(d))
+
+    def kernels_only(self):
+        # every label exactly 3 launches, in the order tools/pmc_traffic.py expects
+        time_kernels(self.model, self.batch, self.args.dtype, reps=2)
+        from imagesegmentation_amd import util
+        polys = [torch.from_numpy(a).to(self.device) for a in rollout_polygons(self.args.rollouts, self.size, 100 + self.rank)]
+        for want_masks in (True, False):
+            for _ in range(3):
+                util.raster_iou(*polys, self.size, want_masks=want_masks)
+        torch.cuda.synchronize()
+
+    # -- legs without collectives ---------------------------------------------------------------------------
+    def raster_leg(self, do_cpu):
+        return bench_raster(self.share["rollouts"], self.size, max(self.args.steps, 5), self.args.warmup, self.device,
+                            self.rank, do_cpu=do_cpu)
+
+    def timeline_steps(self, n):
+        """n more training steps (collectives as in any step) with events around every cell launch."""
+        from imagesegmentation_amd import ops
+        with ops.timeline() as tl:
+            for _ in range(n):
+                self.train_step()
+        return tl.summary()
+
+    def kernel_rooflines(self, in_step):
+        args = self.args
+        kernels = time_kernels(self.model, self.batch, args.dtype, in_step=in_step)
+        # the committed counter passes were taken at the default workload only
+        default_shape = (args.config == "rnnconv" and self.share["batch"] == 64 and self.size == 224 and
+                         args.dtype == "bf16")
+        traffic = load_pmc_traffic() if default_shape else {}
+        for k in kernels:
+            k["traffic"] = traffic.get(k["kernel"])
+        # The dominant kernel = the GPU function with the most time in a step (launches per step x duration).  ``ms``
+        # is the mean duration of the label's REGULAR launches inside a step: the two sequence-end instantiations
+        # (out of the zero state; no incoming state gradient) move fewer bytes and are timed under labels of their own.
+        dom = max(kernels, key=lambda k: k["ms"])
+        roofline = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                    "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["kernel"],
+                    "symbol": {"bwd_fused": "convlstm_bwd_fused_kernel", "cell_fwd": "conv3x3_pp_kernel",
+                               "pointwise_bwd": "lstm_pointwise_bwd_kernel", "dgrad": "conv3x3_pp_kernel",
+                               "wgrad": "conv_wgrad_pp_kernel"}.get(dom["kernel"].split("[")[0]),
+                    "launches_per_step": self.T, "ms_per_launch": dom["ms"], "algorithmic_bytes": dom["bytes"],
+                    "flops": dom["flops"], "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"],
+                    "instantiation": "regular (neither end of the sequence)",
+                    "in_step_ms_by_label": {k: round(v, 4) for k, v in sorted(in_step.items())}}
+        return kernels, roofline
+
+    def cpu_baseline(self):
+        return cpu_baseline_convlstm(self.model, self.batch, self.size, self.T, self.hist, self.head_size)
+
+    def decode_leg(self):
+        """Autoregressive decode of the EndTokenDeep_2 net at 28 x 28 (reference polyrnn/Model.py:231-249,
+        EndTokenDeepExperiment_2.py:150-170): milliseconds per decoded batch and per sequence, launches per vertex."""
+        from imagesegmentation_amd import data
+        from imagesegmentation_amd.polyrnn import experiments
+        model = experiments.make("EndTokenDeep_2", image_size=28, compute_dtype=self.dtype, device=self.device, seed=0)
+        ds = data.PolygonDataset.synthetic(64, 28, 28, model.max_timesteps, model.history_length, seed=50 + self.rank,
+                                           end_token=True)
+        out = {"net": "EndTokenDeep_2", "size": 28, "max_timesteps": model.max_timesteps}
+        rs = np.random.RandomState(60 + self.rank)
+        for B in (16, 2048):
+            idx = rs.randint(0, len(ds), [B])
+            images = torch.as_tensor(ds._images[idx], device=self.device).to(self.dtype)
+            verts = [ds._vertices[i] for i in idx]
+            for _ in range(2):
+                model.validate_iou(images, verts, summary_prefix=None)
+            torch.cuda.synchronize()
+            reps = 5 if B <= 64 else 2
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                iou = model.validate_iou(images, verts, summary_prefix=None)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            out["B%d" % B] = {"ms_per_decode": ms, "ms_per_sequence": ms / B, "sequences_per_s": B / ms * 1e3,
+                              "mean_iou_untrained": iou}
+        out["launches_per_vertex"] = getattr(model, "decode_launches_per_step", None)
+        return out
+
+    # -- legs with collectives (training steps / RL updates inside) --------------------------------------------
+    def reinforce_leg(self):
+        return bench_reinforce(self.share["rl_envs"], 3, self.device, self.rank, self.dtype)
+
+    def a3c_leg(self):
+        return bench_a3c(self.share["a3c_envs"], 2, self.device, self.rank, self.dtype)
+
+    def release(self):
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def full_length_variant(self):
+        return dict(durations=np.full_like(self.batch["durations"], self.T))
+
+    def f32_variant(self):
+        from imagesegmentation_amd.polyrnn import experiments
+        m32 = experiments.make(CONFIGS[self.args.config][0], image_size=self.size, compute_dtype=torch.float32,
+                               device=self.device, seed=0, head_size=self.head_size)
+        return dict(model=m32, batch=dict(self.batch, images=self.batch["images"].float()))
+
+    def other_config_variant(self):
+        """The config this run is not on, at its own default shape (28 x 28, 32 sequences per GPU for EndTokenDeep_2;
+        skipped when this run is EndTokenDeep_2 already)."""
+        if self.args.config != "rnnconv":
+            return None
+        graph, size, batch = CONFIGS["endtokendeep2"]
+        if self.args.scaling == "strong":  # the reference config's global batch of 256, split over the ranks
+            batch = max(256 // self.world, 1)
+        model, bt = self._make(graph, size, batch, self.dtype, seed=70 + self.rank)
+        return dict(model=model, batch=bt, label="%s %dx%d, %d sequences per GPU, T=%d, L=%d" %
+                    (graph, size, size, batch, model.max_timesteps, len(model.rnn.cells)), batch_size=batch)
+
+    def fresh_batch_stepper(self):
+        """A step that builds its batch first (reference polyrnn/EndTokenDeepExperiment_2.py:224-227 calls
+        get_batch_for_rnn before every train): the dataset lives on the device, a batch is one gather of the images and
+        one isg_batch_points launch; lengths stay on the device (every step of the sequence runs under the mask)."""
+        from imagesegmentation_amd import data
+        builder = data.DeviceBatchBuilder(self.batch["dataset"], self.device, image_dtype=self.dtype)
+        scale, T, B, model = self.size // self.head_size, self.T, self.share["batch"], self.model
+
+        def step():
+            b = builder.get_batch_points(B, device_draw=True, seed=80 + self.rank)
+            return model.train_step(b["images"], b["durations"].clamp(max=T), b["points"], b["targets"] // scale)
+        return step
+
+
+class StubWorkload:
+    """--launch-check: the legs as stand-ins that do no GPU work and issue, through the same ``parallel`` helpers the
+    real legs use, the collectives the real legs issue - on gloo host tensors.  A training step is a backward pass
+    through a toy net whose last layer closes a flat gradient bucket (``parallel.EarlyTailReduce``: the tail
+    all-reduced from the autograd hook, the remainder after the backward); an RL update is one
+    ``parallel.allreduce_gradients_`` of a flat bucket.  Before every collective the ranks compare what they are
+    about to issue and fail with a message when they differ."""
+
+    def __init__(self, args, world, rank, local_rank):
+        import datetime
+        import torch.distributed as dist
+        from imagesegmentation_amd import parallel
+        self.args, self.world, self.rank = args, world, rank
+        self.issued = 0
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("ISG_DIST_BACKEND", "gloo"), timeout=datetime.timedelta(seconds=60))
+            self._guard(dist)
+        if os.environ.get("ISG_BENCH_FAIL_RANK") == str(rank):
+            raise SystemExit("rank %d asked to fail (ISG_BENCH_FAIL_RANK)" % rank)
+        self.comm = Comm(world, "cpu", lambda: None)
+        self.share = per_rank(args, world)
+        self.T = 5
+        g = torch.Generator().manual_seed(3)
+        self._a = torch.nn.Parameter(torch.randn(5, 4, generator=g))
+        self._b = torch.nn.Parameter(torch.randn(4, 3, generator=g))
+        self._flat = torch.zeros([self._a.numel() + self._b.numel()])
+        self._a.grad = self._flat[:20].view_as(self._a)
+        self._b.grad = self._flat[20:].view_as(self._b)
+        self._early = parallel.EarlyTailReduce(self._flat, [self._b], 20)
+        self._x = torch.randn(7, 5, generator=torch.Generator().manual_seed(50 + rank))
+        self._rl_flat = torch.zeros([16])
+        self._parallel = parallel
+
+    def _guard(self, dist):
+        """Wraps all_reduce / barrier: the ranks first exchange a tag of the collective each is about to issue."""
+        world = self.world
+        gather = dist.all_gather_object
+
+        def guarded(fn, name):
+            def wrapper(*a, **k):
+                tag = "%s#%d:%s" % (name, self.issued, a[0].numel() if a and torch.is_tensor(a[0]) else "")
+                tags = [None] * world
+                gather(tags, tag)
+                if len(set(tags)) != 1:
+                    raise RuntimeError("ranks disagree on the next collective: %s" % tags)
+                self.issued += 1
+                return fn(*a, **k)
+            return wrapper
+        dist.all_reduce = guarded(dist.all_reduce, "all_reduce")
+        dist.barrier = guarded(dist.barrier, "barrier")
+        self._gather = gather
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            counts = [None] * self.world
+            self._gather(counts, self.issued)
+            if len(set(counts)) != 1:
+                raise RuntimeError("ranks issued different numbers of collectives: %s" % counts)
+            dist.destroy_process_group()
+
+    def train_step(self, model=None, batch=None, durations=None):
+        time.sleep(0.001 * (self.rank + 1))
+        self._flat.zero_()
+        self._early.arm()
+        loss = (torch.tanh(self._x @ self._a) @ self._b).square().sum()
+        loss.backward()
+        self._early.finish(average=True)
+        return loss.detach()
+
+    def _rl_update(self):
+        self._parallel.allreduce_gradients_(self._rl_flat, average=False)
+
+    def describe(self):
+        return {"workload": "launch check (no GPU work)", "mean_duration": float(self.T)}
+
+    def allreduce_bytes(self):
+        return int(self._flat.numel() * 4)
+
+    def conv_flops_per_sequence(self, model=None, durations=None):
+        return 0.0
+
+    def raster_leg(self, do_cpu):
+        return {"ms_per_launch": 1.0 + self.rank, "rollouts": self.share["rollouts"], "rollouts_per_s": 0.0}
+
+    def timeline_steps(self, n):
+        for _ in range(n):
+            self.train_step()
+        return {}
+
+    def kernel_rooflines(self, in_step):
+        return None, None
+
+    def cpu_baseline(self):
+        return None
+
+    def decode_leg(self):
+        return None
+
+    def reinforce_leg(self):
+        # bench_reinforce: one warm-up step, 3 rollouts (no exchange), 3 steps with the update
+        for _ in range(1 + 3):
+            self._rl_update()
+        return {"ms_per_step": 1.0 + self.rank, "rollouts_per_s_rollout_only": 0.0, "envs": self.share["rl_envs"]}
+
+    def a3c_leg(self):
+        # bench_a3c: one warm-up update, 2 timed ones
+        for _ in range(1 + 2):
+            self._rl_update()
+        return {"env_steps_per_s": 1.0, "envs": self.share["a3c_envs"]}
+
+    def release(self):
+        pass
+
+    def full_length_variant(self):
+        return {}
+
+    def f32_variant(self):
+        return {}
+
+    def other_config_variant(self):
+        return dict(label="stand-in", batch_size=32)
+
+    def fresh_batch_stepper(self):
+        return self.train_step
+
+
+def run_legs(args, world, rank, w):
+    """The run, identical on every rank.  Returns the JSON line's record (used on rank 0)."""
+    comm, share = w.comm, w.share
+    # (An earlier build launched kernels 10x slower for the first ~8 s of a process started right behind another
+    # GPU-heavy one, and idled here by default.  It went away with the vendor convolutions - the encoder's solver
+    # search ran inside the first steps of every process.  The switch stays for diagnosis.)
+    if args.settle_seconds > 0:
+        note("settling pause of %.0f s" % args.settle_seconds)
+        comm.sync()
+        time.sleep(args.settle_seconds)
+    note("model and batch ready; warm-up")
+    for _ in range(args.warmup):
+        w.train_step()
+    note("timing %d training steps" % args.steps)
+    comm.fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(0.001 * (rank + 1))
+        loss = w.train_step()
+    comm.fence()
+    elapsed = comm.max(time.perf_counter() - t0)
+    ranks_seen = int(round(comm.sum(1.0)))
+    seqs = share["batch"] * world * args.steps
+
+    def time_steps(step, n, warm):
+        """(seconds per step, MAX over ranks) of n calls of ``step`` after ``warm`` untimed ones, fenced like the
+        headline region.  Every rank calls this with the same n and warm."""
+        for _ in range(warm):
+            step()
+        comm.fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        comm.fence()
+        return comm.max(time.perf_counter() - t0) / n
+
+    note("training leg done: %.3f ms/step; rasteriser leg (with its CPU baseline unless disabled)" %
+         (elapsed / args.steps * 1e3))
+    # ---- rasteriser / IoU leg (sharded rollouts, no collective inside) ---------------------------------------
+    raster = w.raster_leg(do_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ranks = torch.ones([1], dtype=torch.float64)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        print(json.dumps({"metric": "launch check (no GPU work)", "value": args.batch * world * args.steps / elapsed,
-                          "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": elapsed / args.steps * 1e3, "ranks_seen": int(ranks.item()),
-                          "launch_check": True}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        raster["ms_per_launch"] = comm.max(raster["ms_per_launch"])
+        raster["rollouts"] = share["rollouts"] * world
+        raster["rollouts_per_s"] = raster["rollouts"] / raster["ms_per_launch"] * 1e3
+
+    rl = None
+    if args.rl_envs > 0:
+        note("REINFORCE leg")
+        rl = w.reinforce_leg()
+        if world > 1:
+            rl["ms_per_step"] = comm.max(rl["ms_per_step"])
+            rl["envs"] = share["rl_envs"] * world
+            rl["rollouts_per_s_with_update"] = rl["envs"] / rl["ms_per_step"] * 1e3
+            rl.pop("rollouts_per_s_rollout_only")
+
+    ac = None
+    if args.a3c_envs > 0:
+        note("actor-critic leg")
+        ac = w.a3c_leg()
+        if world > 1:
+            ac["env_steps_per_s"] = comm.sum(ac["env_steps_per_s"])
+            ac["envs"] = share["a3c_envs"] * world
+
+    kernels, roofline, cpu = None, None, None
+    if not args.no_kernel_timing:
+        note("per-kernel timing")
+        in_step = w.timeline_steps(2)  # training steps: on every rank
+        if os.environ.get("ISG_BENCH_INJECT") == "rank0_step" and rank == 0:
+            w.train_step()  # fault injection for the launch check's own test: a step only rank 0 takes
+        if rank == 0:
+            kernels, roofline = w.kernel_rooflines(in_step)  # isolated launches, no collective
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("CPU baseline of the training step (bounded sample)")
+        cpu = w.cpu_baseline()
+
+    extra = None
+    if not args.no_extra_runs:
+        w.release()
+        extra = {}
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        note("extra leg: every sequence at full length (durations = T)")
+        full = w.full_length_variant()
+        # (this leg follows a dozen seconds of CPU-only work: a few more warm-up steps bring the clocks back up)
+        sec = time_steps(lambda: w.train_step(**full), max(args.steps // 2, 3), 6)
+        extra["all_durations_T"] = {"value": share["batch"] * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                                    "dtype": args.dtype, "convlstm_mfma_frac_of_step":
+                                        w.conv_flops_per_sequence(durations=full.get("durations")) * share["batch"] /
+                                        sec / 1e12 / peak}
+        note("extra leg: a fresh batch from the device-resident dataset in every step")
+        fresh = w.fresh_batch_stepper()
+        sec = time_steps(fresh, max(args.steps // 2, 3), 2)
+        extra["fresh_batches"] = {"value": share["batch"] * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                                  "dtype": args.dtype, "batch_source": "data.DeviceBatchBuilder (one gather + one "
+                                  "isg_batch_points launch per step; lengths stay on the device, all T steps run masked)"}
+        del fresh
+        if args.dtype == "bf16":
+            note("extra leg: the same step in f32 (f32 MFMA, three-kernel backward)")
+            find = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = False  # no solver search for a three-step leg
+            v32 = w.f32_variant()
+            sec = time_steps(lambda: w.train_step(**v32), 3, 1)
+            extra["f32"] = {"value": share["batch"] * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                            "dtype": "f32", "convlstm_mfma_frac_of_step":
+                                w.conv_flops_per_sequence(model=v32.get("model")) * share["batch"] / sec / 1e12 /
+                                MFMA_PEAK_TFLOPS["f32"]}
+            del v32
+            torch.backends.cudnn.benchmark = find
+            w.release()
+        other = w.other_config_variant()
+        if other is not None:
+            note("extra leg: %s" % other["label"])
+            label, bsz = other.pop("label"), other.pop("batch_size")
+            sec = time_steps(lambda: w.train_step(**other), 10, 3)
+            extra["endtokendeep2"] = {"value": bsz * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
+                                      "dtype": args.dtype, "workload": label, "global_batch": bsz * world}
+            del other
+            w.release()
+        if rank == 0:
+            note("extra leg: autoregressive decode latency")
+            extra["decode"] = w.decode_leg()  # no collective
+    comm.fence()  # nobody tears the process group down while another rank is still inside a leg
+
+    return {
+        "metric": "polygon seqs/sec fwd+bwd (ConvLSTM, 224²) & IoU rollouts/sec",
+        "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": dict(w.describe(), global_batch=share["batch"] * world, parallelism="dp%d" % world),
+        "ranks_seen": ranks_seen, "allreduce_bytes": w.allreduce_bytes(),
+        "convlstm_mfma_frac_of_step": w.conv_flops_per_sequence() * share["batch"] * world / (elapsed / args.steps) /
+        1e12 / (MFMA_PEAK_TFLOPS[args.dtype] * world),
+        "loss": float(loss),
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "extra_runs": extra,
+        "iou": raster, "reinforce": rl, "a3c": ac,
+    }
 
 
 def main():
@@ -445,204 +932,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match the %d ranks of the launcher" % (args.gpus, world))
-    if args.launch_check:
-        return launch_check(args, world, rank)
-    # rehearsal on a box with fewer GPUs than ranks: ISG_DIST_BACKEND=gloo lets several ranks share a device
-    backend = os.environ.get("ISG_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    if not args.no_miopen_find:
-        torch.backends.cudnn.benchmark = True
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=device)
-        else:
-            torch.distributed.init_process_group(backend)
-
-    from imagesegmentation_amd.polyrnn import experiments
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    size, head_size = args.size, 28 if args.size % 28 == 0 else args.size
-    model = experiments.make("RNNConv", image_size=size, compute_dtype=dtype, device=device, seed=0,
-                             head_size=head_size)
-    T, hist = model.max_timesteps, model.history_length
-    batch = make_batch(size, args.batch, T, hist, head_size, seed=rank, device=device, dtype=dtype)
+    w = (StubWorkload if args.launch_check else GpuWorkload)(args, world, rank, local_rank)
     if args.kernels_only:
-        # every label exactly 3 launches, in the order tools/pmc_traffic.py expects
-        time_kernels(model, batch, args.dtype, reps=2)
-        from imagesegmentation_amd import util
-        polys = [torch.from_numpy(a).to(device) for a in rollout_polygons(args.rollouts, size, 100 + rank)]
-        for want_masks in (True, False):
-            for _ in range(3):
-                util.raster_iou(*polys, size, want_masks=want_masks)
-        torch.cuda.synchronize()
-        return
-
-    def step():
-        return model.train_step(batch["images"], batch["durations"], batch["points"], batch["targets"])
-
-    # (An earlier build launched kernels 10x slower for the first ~8 s of a process started right behind another
-    # GPU-heavy one, and idled here by default.  It went away with the vendor convolutions - the encoder's solver
-    # search ran inside the first steps of every process: two full default runs back to back now time 10.73 and
-    # 10.67 ms per step without any pause.  The switch stays for diagnosis.)
-    if args.settle_seconds > 0:
-        note("settling pause of %.0f s" % args.settle_seconds)
-        torch.cuda.synchronize()
-        time.sleep(args.settle_seconds)
-    note("model and batch ready; warm-up")
-    for _ in range(args.warmup):
-        step()
-    note("timing %d training steps" % args.steps)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    seqs = args.batch * world * args.steps
-
-    note("training leg done: %.3f ms/step; rasteriser leg (with its CPU baseline unless disabled)" % (elapsed / args.steps * 1e3))
-    # ---- rasteriser / IoU leg (sharded rollouts, no collective) ------------------------------
-    raster = bench_raster(args.rollouts, size, max(args.steps, 5), args.warmup, device, rank,
-                          do_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-    if world > 1:
-        r = torch.tensor([raster["ms_per_launch"]], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.MAX)
-        raster["ms_per_launch"] = float(r.item())
-        raster["rollouts_per_s"] = args.rollouts * world / raster["ms_per_launch"] * 1e3
-        raster["rollouts"] = args.rollouts * world
-
-    rl = None
-    if args.rl_envs > 0:
-        note("REINFORCE leg")
-        rl = bench_reinforce(args.rl_envs, 3, device, rank, dtype)
-        if world > 1:
-            r = torch.tensor([rl["ms_per_step"]], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.MAX)
-            rl["ms_per_step"] = float(r.item())
-            rl["envs"] = args.rl_envs * world
-            rl["rollouts_per_s_with_update"] = rl["envs"] / rl["ms_per_step"] * 1e3
-            rl.pop("rollouts_per_s_rollout_only")
-
-    ac = None
-    if args.a3c_envs > 0:
-        note("actor-critic leg")
-        ac = bench_a3c(args.a3c_envs, 2, device, rank, dtype)
-        if world > 1:
-            r = torch.tensor([ac["env_steps_per_s"]], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(r, op=torch.distributed.ReduceOp.SUM)
-            ac["env_steps_per_s"] = float(r.item())
-            ac["envs"] = args.a3c_envs * world
-
-    kernels, roofline, cpu = None, None, None
-    if rank == 0 and not args.no_kernel_timing:
-        note("per-kernel timing")
-        from imagesegmentation_amd import ops
-        with ops.timeline() as tl:  # two more steps, outside the timed region, with events around every cell launch
-            for _ in range(2):
-                step()
-        kernels = time_kernels(model, batch, args.dtype, in_step=tl.summary())
-        # the committed counter passes were taken at the default workload only
-        default_shape = args.batch == 64 and args.size == 224 and args.dtype == "bf16"
-        traffic = load_pmc_traffic() if default_shape else {}
-        for k in kernels:
-            k["traffic"] = traffic.get(k["kernel"])
-        # The dominant kernel = the GPU function with the most time in a step.  Every label below is its own
-        # template instantiation and runs T times per step.
-        dom = max(kernels, key=lambda k: k["ms"])
-        roofline = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                    "frac": dom["frac"], "traffic": dom["traffic"], "kernel": dom["kernel"],
-                    "symbol": {"bwd_fused": "convlstm_bwd_fused_kernel", "cell_fwd": "conv3x3_pp_kernel",
-                               "pointwise_bwd": "lstm_pointwise_bwd_kernel", "dgrad": "conv3x3_pp_kernel",
-                               "wgrad": "conv_wgrad_pp_kernel"}.get(dom["kernel"].split("[")[0]),
-                    "launches_per_step": T, "ms_per_launch": dom["ms"], "algorithmic_bytes": dom["bytes"],
-                    "flops": dom["flops"], "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        note("CPU baseline of the training step (bounded sample)")
-        cpu = cpu_baseline_convlstm(model, batch, size, T, hist, head_size)
-
-    extra = None
-    if not args.no_extra_runs:
-        import gc
-        gc.collect()
-        torch.cuda.empty_cache()
-        extra = {}
-        note("extra leg: every sequence at full length (durations = T)")
-        full = np.full_like(batch["durations"], T)
-
-        def time_steps(m, bt, durations, n, warm):
-            for _ in range(warm):
-                m.train_step(bt["images"], durations, bt["points"], bt["targets"])
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                m.train_step(bt["images"], durations, bt["points"], bt["targets"])
-            fence()
-            el = time.perf_counter() - t0
-            if world > 1:
-                tm = torch.tensor([el], device=device, dtype=torch.float64)
-                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-                el = float(tm.item())
-            return el / n
-
-        conv_flops = lambda m, dur: 3.0 * sum(2.0 * size * size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
-                                              for c in m.rnn.cells) * float(np.mean(dur))
-        # (this leg follows a dozen seconds of CPU-only work: a few more warm-up steps bring the clocks back up)
-        sec = time_steps(model, batch, full, max(args.steps // 2, 3), 6)
-        extra["all_durations_T"] = {"value": args.batch * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
-                                    "dtype": args.dtype, "convlstm_mfma_frac_of_step":
-                                        conv_flops(model, full) * args.batch / sec / 1e12 / MFMA_PEAK_TFLOPS[args.dtype]}
-        if args.dtype == "bf16":
-            note("extra leg: the same step in f32 (f32 MFMA, three-kernel backward)")
-            find = torch.backends.cudnn.benchmark
-            torch.backends.cudnn.benchmark = False  # no solver search for a three-step leg
-            m32 = experiments.make("RNNConv", image_size=size, compute_dtype=torch.float32, device=device, seed=0,
-                                   head_size=head_size)
-            b32 = dict(batch, images=batch["images"].float())
-            sec = time_steps(m32, b32, batch["durations"], 3, 1)
-            extra["f32"] = {"value": args.batch * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
-                            "dtype": "f32", "convlstm_mfma_frac_of_step":
-                                conv_flops(m32, batch["durations"]) * args.batch / sec / 1e12 / MFMA_PEAK_TFLOPS["f32"]}
-            del m32, b32
-            torch.backends.cudnn.benchmark = find
-            torch.cuda.empty_cache()
-
+        w.kernels_only()
+        return w.close()
+    line = run_legs(args, world, rank, w)
+    if args.launch_check:
+        line.update(metric="launch check (no GPU work)", launch_check=True)
+    w.close()  # (the launch check compares the ranks' collective counts here, before anything is printed)
     if rank == 0:
-        flop_seq = 3.0 * sum(2.0 * size * size * 9 * (c.input_to_state_kernel.shape[2] + 16) * 64
-                             for c in model.rnn.cells) * float(np.mean(batch["durations"]))
-        line = {
-            "metric": "polygon seqs/sec fwd+bwd (ConvLSTM, 224²) & IoU rollouts/sec",
-            "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "polyrnn RNNConvExperiment graph, teacher-forced training step "
-                                   "(fwd+bwd+clip+Adam), %dx%d synthetic polygons, batch %d per GPU, T=%d, "
-                                   "2xConvLSTM(16), dense head on the 8x-pooled %dx%d grid" %
-                                   (size, size, args.batch, T, head_size, head_size),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "mean_duration": float(np.mean(batch["durations"]))},
-            "convlstm_mfma_frac_of_step": flop_seq * args.batch * world / (elapsed / args.steps) / 1e12 /
-            (MFMA_PEAK_TFLOPS[args.dtype] * world),
-            "loss": float(loss),
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "extra_runs": extra,
-            "iou": raster, "reinforce": rl, "a3c": ac,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,7 @@ SIGNATURES = {
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),
     "isg_relu_bwd_bias": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_relu_bwd_bias_static": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp]),
+    "isg_relu_bwd_bias_static_init": (_int, []),
     "isg_conv_in_packed_elems": (_ll, [_int, _int]),
     "isg_conv_in_pack": (_int, [_vp, _int, _int, _vp, _vp]),
     "isg_conv_in_pad_image": (_int, [_vp, _ll, _vp, _vp]),

@@ -325,7 +325,11 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=torch.float32, device=dev).unbind(0)))
     # What a layer keeps for backward (next to its states): the backward factors where the fused backward step
     # exists for its shape, else the gate activations for the three-kernel backward.
-    layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W) else ops.SAVE_GATES for l in range(L)]
+    # (Layer 0's input gradient has the width of the static features when the input is the tiled form: the fused
+    # step writes it in runs of 8 channels, other widths take the three-kernel backward.)
+    dx0 = seq.static.shape[-1] if seq.x_seq is None else None
+    layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W, dx0 if l == 0 else None)
+               else ops.SAVE_GATES for l in range(L)]
     Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, layouts[l]), dtype=dt, device=dev) for l in range(L)] \
         if save else None
     # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
@@ -339,9 +343,9 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
         x = seq.get(t)
         nxt = cur + 1 if save else (2 if cur == 1 else 1)
         for l in range(L):
-            ops.set_layer(l)
             top = l == L - 1
             first = t == 0 and from_zero[l]
+            ops.set_layer(l, ",zs" if first else "")
             ops.cell_fwd(x, None if first else Hs[l][cur], None if first else Cs[l][cur], packed[l], durations_dev, t,
                          out=out[:, t] if top and not fused_pool else None, out_batch_stride=T * H * W * F,
                          save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
@@ -350,6 +354,7 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
                          pool=pool)
             x = Hs[l][nxt]
         cur = nxt
+    ops.set_layer(0)
     if pool > 1 and not fused_pool:
         out = ops.avgpool(out, pool)
     if cur == 0:  # no step ran: hand out copies, never the shared zero tensors or the caller's own state
@@ -486,6 +491,9 @@ class _SequenceFunction(torch.autograd.Function):
         cells = list(ctx.multi.cells)
         L = len(cells)
         seq, durations_dev, t_run = ctx.seq, ctx.durations_dev, ctx.t_run
+        if ctx.saved is None:
+            raise RuntimeError("the recurrence's sequence node runs backward once (its saved states are released "
+                               "after the sweep): run the forward pass again instead of retain_graph=True")
         Hs, Cs, Gs, packed, layouts = ctx.saved
         dt = cells[0].compute_dtype
         B, H, W, F, T = seq.B, seq.H, seq.W, cells[0]._filters, seq.T
@@ -558,6 +566,7 @@ class _SequenceFunction(torch.autograd.Function):
                     # wants the gradient of that state
                     first = t == 0 and ctx.state_dtypes[l] == (None, None) and not os.environ.get("ISG_NO_ZERO_STATE")
                     last = t == t_run - 1 and no_carry[l]
+                    ops.set_layer(l, (",zs" if first else "") + (",edge" if last else ""))
                     ops.bwd_fused(Gs[l][t], None if first else Cs[l][t], Hs[l][t + 1], above, stride,
                                   None if last else dh_state[l], None if last else dc_state[l], x_in,
                                   None if first else Hs[l][t], packed[l],
@@ -572,6 +581,7 @@ class _SequenceFunction(torch.autograd.Function):
                 ops.wgrad(x_in, Hs[l][t], dy, packed[l].c, grads[l][0], grads[l][1], grads[l][2], True, durations_dev, t,
                           hist_points=pts, hist=packed[l].hist, mode=mode, workspace=slabs[l])
                 ops.dgrad(dy, packed[l], dh_state[l], durations=durations_dev, t=t, **dx_args)
+        ops.set_layer(0)
         if t_run > 0:
             for l in range(L):
                 ops.wgrad_finish(slabs[l], (B, H, W, packed[l].cs), packed[l].c, packed[l].hist, *grads[l])
@@ -676,6 +686,9 @@ class _WideSequenceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_c, d_h):
         cell, durations_dev, t_run, C = ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C
+        if ctx.saved is None:
+            raise RuntimeError("the recurrence's sequence node runs backward once (its saved states are released "
+                               "after the sweep): run the forward pass again instead of retain_graph=True")
         xw, Hs, Cs, Gs, groups, layout = ctx.saved
         Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
         k = F // Fh
@@ -793,6 +806,8 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, time_maj
     [.., H/k, W/k, F], and the pool's gradient is applied inside the recurrence's backward sweep.
     ``steps`` (not in TensorFlow): an upper bound of the lengths known to the caller, for lengths given as a
     device tensor - that many steps run instead of fetching the longest length from the device.
+    The whole recurrence is one autograd node that releases what it saved once its backward has run: a second
+    backward through the same forward pass (``retain_graph=True``) raises.
     """
     multi = cell if isinstance(cell, MultiRNNCell) else MultiRNNCell([cell])
     if isinstance(inputs, SequenceInput):

@@ -427,8 +427,11 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                             for (int k = 0; k < 4; ++k)
                                 fk[k] = (ch & 1) ? bf_hi(fw[4 * (ch >> 1) + k]) : bf_lo(fw[4 * (ch >> 1) + k]);
                             const float fg = fk[2], og = fk[3], h = hv[ch];
-                            // o (1 - tanh(c)^2) with tanh(c) = h / o  (o = 0 only where h = 0 too: the guard keeps 0 * inf away)
-                            const float e = og - h * (h * __builtin_amdgcn_rcpf(fmaxf(og, 1e-30f)));
+                            // o (1 - tanh(c)^2) with tanh(c) = h / o  (o = 0 only where h = 0 too: the guard keeps 0 * inf away).
+                            // h and o arrive rounded to bf16: for a saturated cell (|tanh c| near 1) the difference
+                            // cancels and may come out slightly negative or above o - the median keeps it in [0, o].
+                            const float e = __builtin_amdgcn_fmed3f(
+                                og - h * (h * __builtin_amdgcn_rcpf(fmaxf(og, 1e-30f))), 0.f, og);
                             const float dh = da[ch] * inv_pool + ds[ch];
                             const float dct = dcp[ch] + dh * e;
                             out[4 * ch] = dct * fk[0];

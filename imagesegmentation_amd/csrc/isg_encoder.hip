@@ -201,9 +201,24 @@ extern "C" int isg_relu_bwd_bias_static(const void* dy, const void* y, long long
                 "isg_relu_bwd_bias_static: %d channels exceed the built-in scratch (at most %d); use "
                 "isg_relu_bwd_bias with a workspace", C, kStaticMaxC);
     ISG_REQUIRE(dbias, ISG_EINVAL, "isg_relu_bwd_bias_static: null pointer");
+    if (stream) {
+        // the scratch handed to the kernels is the CURRENT device's copy: a stream of another GPU would get a
+        // pointer that is not its own
+        int cur = -1, sdev = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e == hipSuccess) e = hipStreamGetDevice(static_cast<hipStream_t>(stream), &sdev);
+        ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "isg_relu_bwd_bias_static: device query: %s", hipGetErrorString(e));
+        ISG_REQUIRE(cur == sdev, ISG_EINVAL,
+                    "isg_relu_bwd_bias_static: the stream belongs to device %d but device %d is current", sdev, cur);
+    }
     float* partial = nullptr;
     if ((rc = static_scratch(&partial)) != ISG_OK) return rc;
     return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, partial, stream);
+}
+
+extern "C" int isg_relu_bwd_bias_static_init(void) {
+    float* partial = nullptr;
+    return static_scratch(&partial);
 }
 
 namespace {

@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void batch_points_kernel(const int* __restrict
     if (gid >= B * slots) return;
     const int b = gid / slots, slot = gid - b * slots;
     const int sample = indices[b];
-    const int n = counts[sample];
+    // The counts live on the device, where the host cannot check them: a polygon of no vertices (or a count past
+    // the table's width) is treated as one of a single vertex / of vcap vertices instead of dividing by zero or
+    // reading past its row.  PolygonDataset never holds either.
+    int n = counts[sample];
+    n = n < 1 ? 1 : (n > vcap ? vcap : n);
     const int* v = table + (size_t)sample * vcap * 2;
     // floor modulo: start vertices may be given negative or beyond n, as np.roll takes them
     const int s = ((starts[b] % n) + n) % n;

@@ -218,6 +218,8 @@ class DeviceBatchBuilder:
         self.device = torch.device(device)
         images = torch.as_tensor(dataset._images)
         self.images = images.to(self.device, dtype=image_dtype if image_dtype is not None else images.dtype)
+        if len(dataset._counts) == 0 or int(dataset._counts.min()) < 1:
+            raise ValueError("every polygon of the dataset needs at least one vertex")
         self.table = ops.upload(dataset._table, self.device, torch.int32).contiguous()
         self.counts = ops.upload(dataset._counts, self.device, torch.int32).contiguous()
         self._generator = None

@@ -85,14 +85,17 @@ def padded_channels(c, dtype):
 # ---- optional in-step timing -------------------------------------------------------------------------
 # ``with timeline() as tl:`` makes every wrapped op record a pair of events on the current stream around its
 # launch(es); ``tl.summary()`` gives mean milliseconds per "op[layerN]" label.  Used by the benchmark to read
-# kernel durations inside a real training step; costs nothing when off.
+# kernel durations inside a real training step; costs nothing when off.  The launches at the two ends of a
+# sequence are other template instantiations that move fewer bytes (out of the zero state: ",zs"; no incoming
+# state gradient: ",edge"): they are filed under labels of their own, "op[layerN,zs]".
 _timeline = None
 _layer = 0
+_variant = ""
 
 
-def set_layer(l):
-    global _layer
-    _layer = l
+def set_layer(l, variant=""):
+    global _layer, _variant
+    _layer, _variant = l, variant
 
 
 class timeline:
@@ -124,7 +127,7 @@ def _timed(name):
             a.record()
             out = fn(*args, **kwargs)
             b.record()
-            tl.records.append(("%s[layer%d]" % (name, _layer), a, b))
+            tl.records.append(("%s[layer%d%s]" % (name, _layer, _variant), a, b))
             return out
         wrapper.__doc__, wrapper.__name__ = fn.__doc__, fn.__name__
         return wrapper
@@ -322,10 +325,13 @@ def wgrad_finish(workspace, shape, c_real, hist, dw_x, dw_h, dbias, accumulate=F
     _lib.check(rc, "isg_convlstm_wgrad_finish")
 
 
-def bwd_fused_supported(packed, B, H, W):
+def bwd_fused_supported(packed, B, H, W, dx_channels=None):
     """Whether the one-launch backward step exists for this cell shape (ISG_NO_FUSED_BWD=1 answers no: the
-    three-kernel backward, for A/B runs)."""
+    three-kernel backward, for A/B runs).  ``dx_channels``: how many channels of the input gradient the caller
+    will ask the step for - it stores them in runs of 8, so a count that is no multiple of 8 answers no."""
     if os.environ.get("ISG_NO_FUSED_BWD"):
+        return False
+    if dx_channels is not None and (dx_channels < 8 or dx_channels % 8 != 0):
         return False
     return bool(_lib.lib().isg_convlstm_bwd_fused_supported(packed.cs, packed.f, dtype_code(packed.dtype), int(B), int(H),
                                                             int(W), packed.hist))

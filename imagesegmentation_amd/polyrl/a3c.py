@@ -129,7 +129,20 @@ class LSTMPolicy:
         self.value_kernel = torch.nn.Parameter(_dense_init((flat, 1), self.device, gen))
         self.value_bias = torch.nn.Parameter(torch.zeros([1], device=self.device))
         self._sample_calls = 0
-        self._seed = parallel.sampling_seed(seed)  # weights above come from `seed` itself: equal on every rank
+        self._base_seed = seed  # weights above come from `seed` itself: equal on every rank
+        self._rank_seed = None
+
+    @property
+    def _seed(self):
+        """The rank's own sampling seed, fixed at the FIRST sampled action: the process group may be initialised
+        after the policy is built, and a seed folded before that would be the same on every rank."""
+        if self._rank_seed is None:
+            import os
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1 and parallel.world_size() == 1:
+                raise RuntimeError("WORLD_SIZE > 1 but no process group is initialised: every rank would sample the "
+                                   "same actions; call torch.distributed.init_process_group first")
+            self._rank_seed = parallel.sampling_seed(self._base_seed)
+        return self._rank_seed
 
     @property
     def var_list(self):

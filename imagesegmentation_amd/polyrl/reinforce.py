@@ -52,8 +52,16 @@ class ExperimentPolicyEstimator(Model):
         sample_seed = kwargs.pop("sample_seed", 0)
         self._sample_calls = 0
         super().__init__(tf_session, max_timesteps, image_size, action_size, 2, kwargs.pop("filepath", None), **kwargs)
-        self._sample_seed = parallel.sampling_seed(sample_seed, self.process_group)  # per-rank action noise
+        self._sample_base, self._sample_rank_seed = sample_seed, None
         self.gradBuffer = torch.zeros_like(self._flat_grad)
+
+    @property
+    def _sample_seed(self):
+        """Per-rank action noise, folded at the first sampled action (a process group initialised after the
+        estimator was built is then already there)."""
+        if self._sample_rank_seed is None:
+            self._sample_rank_seed = parallel.sampling_seed(self._sample_base, self.process_group)
+        return self._sample_rank_seed
 
     # -- acting ----------------------------------------------------------------------------------
     def get_rnn_zero_state(self, batch_size):
@@ -159,13 +167,66 @@ def play_episode(env, policy_estimator, max_timesteps=None):
     return trajectory
 
 
-def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_per_episode=None, summary_writer=None,
-              validate_every=None):
-    """The reference's scalar training loop (polyrl/ReinforceOverfitExperiment.py:279-331): episode after
-    episode; an episode whose last step earned a reward (:306) adds its policy gradient, with discounted
-    returns as weights, to the estimator's buffer; the buffer is applied on every fifth episode but the
-    first (:312).  ``sess``, ``summary_writer`` and ``validate_every`` are accepted for the call shape only.
+def validate_episode_iou(policy_estimator, env, max_timesteps_per_episode=None, summary_prefix='valid'):
+    """The estimator's environment-driven validation (reference polyrl/ReinforceOverfitExperiment.py:224-261): one
+    episode under the sampling policy, then the IoU of the polygon [last ``hist`` true vertices ++ the actions
+    taken] against the true polygon.  Returns the IoU (also kept as ``policy_estimator.last_ious`` and written to
+    the estimator's scalar log under ``<prefix>/iou``)."""
+    from .. import util
+    trajectory = play_episode(env, policy_estimator, max_timesteps_per_episode)
+    true_vertices = np.asarray(env.vertices)
+    hist = policy_estimator.history_length
+    predicted = np.concatenate([true_vertices[len(true_vertices) - hist:], np.vstack(trajectory.actions)], axis=0)
+    P = policy_estimator.action_size
+    # (an end-token action (P, 0) is a vertex like any other here, as in the reference, whose mask[rr, cc] = 1 then
+    # raises IndexError for column P - util.calculate_iou raises the same)
+    iou = util.calculate_iou(predicted.astype(np.int64), true_vertices.astype(np.int64), P)
+    policy_estimator.last_ious = np.array([iou])
+    tag = summary_prefix + '/iou' if summary_prefix else 'iou'
+    policy_estimator._add_summaries(summary_prefix or 'valid', extra={tag: float(iou)})
+    return float(iou)
+
+
+def reinforce(*args, **kwargs):
+    """The reference's scalar training loop in both of its call shapes:
+
+    * ``reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_per_episode=None,
+      summary_writer=None)`` - polyrl/ReinforceOverfitEndTokenExperiment.py:277 (called by keyword at its :352);
+    * ``reinforce(train_env, valid_env, sess, policy_estimator, total_episodes=None,
+      max_timesteps_per_episode=None, summary_writer=None)`` - polyrl/ReinforceOverfitExperiment.py:279 (called by
+      keyword at its :358).
+
+    Episode after episode; an episode whose last step earned a reward (:306) adds its policy gradient, with
+    discounted returns as weights, to the estimator's buffer; the buffer is applied on every fifth episode but
+    the first (:312).  ``validate_every=n`` (keyword, not in the reference, default off) runs the reference's
+    validation episodes - on the training environment, and on ``valid_env`` when there is one - on every n-th
+    episode from episode 0 on (the reference's n is 100, its :326-331); they draw from ``np.random`` through
+    ``env.reset`` like the reference's.  ``sess`` and ``summary_writer`` are accepted for the call shape only.
     Returns the list of episode rewards."""
+    names = ("env", "sess", "policy_estimator", "total_episodes", "max_timesteps_per_episode", "summary_writer")
+    two_envs = "train_env" in kwargs or "valid_env" in kwargs or \
+        (len(args) >= 2 and hasattr(args[1], "reset") and hasattr(args[1], "step"))
+    if two_envs:
+        names = ("train_env", "valid_env") + names[1:]
+    names += ("validate_every",)
+    if len(args) > len(names):
+        raise TypeError("reinforce() takes at most %d positional arguments (%d given)" % (len(names), len(args)))
+    bound = dict(zip(names, args))
+    for k, v in kwargs.items():
+        if k not in names:
+            raise TypeError("reinforce() got an unexpected keyword argument %r" % k)
+        if k in bound:
+            raise TypeError("reinforce() got multiple values for argument %r" % k)
+        bound[k] = v
+    for k in names[:4 if two_envs else 3]:
+        if k not in bound:
+            raise TypeError("reinforce() missing required argument %r" % k)
+    env = bound["train_env"] if two_envs else bound["env"]
+    valid_env = bound.get("valid_env")
+    policy_estimator = bound["policy_estimator"]
+    total_episodes = bound.get("total_episodes")
+    max_timesteps_per_episode = bound.get("max_timesteps_per_episode")
+    validate_every = bound.get("validate_every")
     episode_rewards = []
     numbering = itertools.count() if total_episodes is None else range(total_episodes)
     for episode in numbering:
@@ -176,6 +237,11 @@ def reinforce(env, sess, policy_estimator, total_episodes=None, max_timesteps_pe
                                     td_targets=discount_rewards(trajectory.rewards),
                                     apply_grads=episode > 0 and episode % 5 == 0)
         episode_rewards.append(trajectory.total_reward)
+        if validate_every and episode % validate_every == 0:
+            validate_episode_iou(policy_estimator, env, max_timesteps_per_episode,
+                                 summary_prefix='train' if two_envs else 'valid')
+            if valid_env is not None:
+                validate_episode_iou(policy_estimator, valid_env, max_timesteps_per_episode, summary_prefix='valid')
     return episode_rewards
 
 

@@ -228,7 +228,8 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  * (384 fewer bytes per pixel than isg_convlstm_pointwise_bwd + _dgrad + _wgrad).  Same results as those three
  * calls up to the bf16 rounding of the factors and the order of float additions.  Replaces the gradient of reference convLSTM.py:36-43 that
  * tf.gradients derives (reference polyrnn/Model.py:108).
- *   Only where isg_convlstm_bwd_fused_supported(...) returns 1: bf16, F = 16, Cs = 16 or 32, hist <= 2.
+ *   Only where isg_convlstm_bwd_fused_supported(...) returns 1: bf16, F = 16, Cs = 16, 32 or 48, hist <= 2; dx (when
+ *   given) in runs of 8 channels: dx_channels and dx_channel_stride multiples of 8.
  *   dc_state / dc_prev are bf16 and must be different buffers, as must dh_state / dh_prev (a tile recomputes its
  *   neighbours' border pixels from the incoming gradients); for a masked sample both pass through as copies
  *   and dx is zero (left alone when accumulating).
@@ -357,8 +358,13 @@ int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dty
  * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  At most ISG_RELU_BWD_BIAS_STATIC_MAX_C channels (more: ISG_EINVAL);
  * results are identical to isg_relu_bwd_bias.  All calls on one GPU share the array: calls that overlap
- * on one GPU (different streams, different threads) race; calls queued on one stream do not. */
+ * on one GPU (different streams, different threads) race; calls queued on one stream do not.
+ * The array used is the CURRENT device's copy: `stream` must belong to the current device (checked:
+ * ISG_EINVAL otherwise).  The address lookup of the first call on a device (hipGetSymbolAddress under a
+ * lock) must not happen inside a stream capture: call isg_relu_bwd_bias_static_init() once per device,
+ * with that device current, before capturing (it does only that lookup and launches nothing). */
 #define ISG_RELU_BWD_BIAS_STATIC_MAX_C 64
+int isg_relu_bwd_bias_static_init(void);
 int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                              void* stream);
 

@@ -1,6 +1,9 @@
 """`python bench.py --gpus N` starts its own ranks: the launch path (children through torch.distributed.run,
-rendezvous on 127.0.0.1, the timed region's barriers and reductions, one JSON line from rank 0, the children's
-exit status) checked here with two gloo ranks and no GPU work (--launch-check)."""
+rendezvous on 127.0.0.1, one JSON line from rank 0, the children's exit status) and the WHOLE control flow of a
+run (bench.run_legs: warm-up, timed region, rasteriser / REINFORCE / actor-critic legs, the per-kernel timing
+steps, the extra legs) checked here with two gloo ranks and no GPU work (--launch-check): every leg is a stand-in
+that issues the collectives the real leg issues, through the same parallel helpers, and the ranks compare what
+they are about to issue before each one."""
 import json
 import os
 import subprocess
@@ -26,6 +29,37 @@ def test_gpus_2_self_launches_two_ranks_and_prints_one_json_line():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["steps"] == 3 and rec["launch_check"]
     # the slower rank (2 ms per empty step) sets the time: MAX over ranks
     assert rec["ms_per_step"] >= 2.0
+
+
+def test_every_leg_ran_and_the_line_carries_the_exchange_facts():
+    p = _run({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--launch-check")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 128 and rec["config"]["parallelism"] == "dp2"
+    assert rec["allreduce_bytes"] > 0
+    assert set(rec["extra_runs"]) == {"all_durations_T", "fresh_batches", "f32", "endtokendeep2", "decode"}
+    assert rec["iou"]["rollouts"] == 2 * 16384 and rec["reinforce"]["envs"] == 2 * 2048 and rec["a3c"]["envs"] == 2 * 1024
+    # MAX over ranks of the stand-in legs' times (rank r reports 1 + r ms)
+    assert rec["iou"]["ms_per_launch"] == 2.0 and rec["reinforce"]["ms_per_step"] == 2.0
+
+
+def test_a_step_that_only_rank_0_takes_is_caught():
+    """The fault this check exists for: a training step (two all-reduces) outside the timed region that only rank 0
+    runs pairs its collectives with whatever the other ranks issue next."""
+    p = _run({"ISG_BENCH_INJECT": "rank0_step"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--launch-check")
+    assert p.returncode != 0
+    assert "ranks disagree on the next collective" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_strong_scaling_splits_the_global_batch():
+    p = _run({}, "--gpus", "2", "--steps", "2", "--warmup", "0", "--launch-check", "--scaling", "strong")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["config"]["global_batch"] == 64
+    assert rec["iou"]["rollouts"] == 16384 and rec["reinforce"]["envs"] == 2048 and rec["a3c"]["envs"] == 1024
+    p = _run({}, "--gpus", "2", "--launch-check", "--scaling", "strong", "--batch", "63")
+    assert p.returncode != 0 and "does not divide" in p.stderr
 
 
 def test_single_rank_needs_no_launcher():

@@ -60,3 +60,25 @@ def test_static_scratch_size_limit_and_empty_input():
     assert rc == 0
     torch.cuda.synchronize()
     assert float(db16.abs().sum()) == 0.0
+
+
+def test_static_scratch_init_and_side_stream():
+    """The warm-up call resolves the built-in array on the current device (what a caller does before a stream
+    capture); a non-default stream of the current device is accepted and gives the same result."""
+    lib = _lib.lib()
+    assert lib.isg_relu_bwd_bias_static_init() == 0
+    dev = torch.device("cuda:0")
+    n, C = 4096, 32
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dy = torch.randn([n, C], generator=g).to(torch.bfloat16).to(dev)
+    y = torch.randn([n, C], generator=g).clamp_min(0).to(torch.bfloat16).to(dev)
+    dz, db = torch.empty_like(dy), torch.empty([C], dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    rc = lib.isg_relu_bwd_bias_static(dy.data_ptr(), y.data_ptr(), n, C, 1, dz.data_ptr(), db.data_ptr(),
+                                      side.cuda_stream)
+    assert rc == 0, lib.isg_last_error()
+    side.synchronize()
+    want = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(dz, want)
+    assert torch.allclose(db.double(), want.double().sum(0), rtol=1e-5, atol=1e-3)
