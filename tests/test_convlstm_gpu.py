@@ -544,6 +544,90 @@ def test_fused_backward_step_matches_the_three_kernel_backward(case, monkeypatch
         assert torch.isfinite(got[key]).all()
 
 
+def test_static_features_that_are_no_multiple_of_8_take_the_three_kernel_backward(monkeypatch):
+    """12 static feature channels + 2 history frames (Cs = 16): the fused backward step writes the input gradient
+    in runs of 8 channels, so layer 0 keeps the gate activations and runs pointwise / dgrad / wgrad while layer 1
+    still takes the fused step; every gradient equals the all-three-kernel run's."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import SequenceInput, dynamic_rnn
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(43)
+    T, B, H, W, Cf, hist, L = 3, 3, 20, 36, 12, 2, 2
+    _, multi = _stack(rs, Cf + hist, L, dtype, (H, W))
+    feat = torch.tensor(rs.randn(B, H, W, Cf), dtype=dtype, device=dev())
+    pts = torch.tensor(rs.randint(0, 20, [B, T, hist, 2]).astype(np.int32), device=dev())
+    durations = np.array([T, 1, 2], np.int32)
+    d_out = torch.tensor(rs.randn(B, T, H, W, 16), dtype=torch.float32, device=dev())
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("ISG_NO_FUSED_BWD", raising=False)
+        else:
+            monkeypatch.setenv("ISG_NO_FUSED_BWD", "1")
+        for cell in multi.cells:
+            for prm in (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias):
+                prm.grad = None
+        leaf = feat.clone().requires_grad_(True)
+        out, _ = dynamic_rnn(multi, SequenceInput(static=leaf, hist_points=pts), sequence_length=durations,
+                             time_major=False)
+        calls = []
+        real = ops.bwd_fused
+        monkeypatch.setattr(ops, "bwd_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        (out.float() * d_out).sum().backward()
+        monkeypatch.setattr(ops, "bwd_fused", real)
+        got = [leaf.grad.float().clone()]
+        for cell in multi.cells:
+            got += [cell.input_to_state_kernel.grad.clone(), cell.hidden_to_state_kernel.grad.clone(), cell.bias.grad.clone()]
+        return got, len(calls)
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == (L - 1) * T  # layer 1 only
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 1e-2 * max(float(b.abs().max()), 1e-6)
+
+
+def test_fused_gate_backward_of_saturated_cells_stays_bounded():
+    """Cells with |c| of 3 to 5 (|tanh c| within 1e-2..1e-4 of 1): the fused step forms o (1 - tanh^2 c) as
+    o - h^2 / o from bf16 o and h, a difference of nearly equal numbers, and keeps it inside [0, o]; dc_prev stays
+    within the same bound of the float64 gate backward as for ordinary cells, in units of the largest value."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell
+    from helpers_convlstm import backward_factors
+    dt, d = torch.bfloat16, dev()
+    B, H, W, F = 2, 16, 32, 16
+    g = torch.Generator(device=d).manual_seed(8)
+    cell = ConvLSTMCell([H, W], 16, [3, 3], compute_dtype=dt, device=d).build(16, d)
+    packed = cell.packed()
+    rnd = lambda *s: torch.randn(list(s), device=d, generator=g)
+    gates = torch.sigmoid(rnd(B, H, W, F, 4))
+    gates[..., 0] = 2 * gates[..., 0] - 1
+    sign = torch.where(rnd(B, H, W, F) > 0, 1.0, -1.0)
+    c1 = sign * (3.0 + 2.0 * torch.rand([B, H, W, F], device=d, generator=g))   # saturated new cell state
+    c0 = rnd(B, H, W, F)
+    fac = backward_factors(gates).to(dt).contiguous()
+    h_cur = (gates[..., 3] * torch.tanh(c1)).to(dt)
+    x, h = rnd(B, H, W, 16).to(dt), rnd(B, H, W, F).to(dt)
+    above = rnd(B, H, W, F).to(dt)
+    dh, dc = rnd(B, H, W, F).to(dt), rnd(B, H, W, F).to(dt)
+    dc2, dh2 = torch.empty_like(dc), torch.empty_like(dh)
+    ws = ops.wgrad_workspace(16, F, d, cached=False)
+    dwx = torch.zeros_like(cell.input_to_state_kernel)
+    ops.bwd_fused(fac, c0, h_cur, above, H * W * F, dh, dc, x, h, packed, dc2, dh2, ws, ops.WGRAD_DEFER_FIRST, dwx)
+    fg, go = gates[..., 2].double(), gates[..., 3].double()
+    tc = torch.tanh(c1.double())
+    E = go * (1 - tc * tc)
+    dht = above.double() + dh.double()
+    want = (dc.double() + dht * E) * fg
+    # what the clamp guarantees: the recomputed E lies in [0, o], so dc_prev lies between the two extremes
+    lo = torch.minimum(dc.double() * fg, (dc.double() + dht * go) * fg)
+    hi = torch.maximum(dc.double() * fg, (dc.double() + dht * go) * fg)
+    tol = 2.0 ** -7 * want.abs().max()
+    assert bool(((dc2.double() >= lo - tol) & (dc2.double() <= hi + tol)).all())
+    assert float((dc2.double() - want).abs().max()) <= 3e-2 * float(want.abs().max())
+    assert torch.isfinite(dc2.float()).all() and torch.isfinite(dh2.float()).all()
+
+
 def test_wide_cell_fused_backward_matches_the_three_kernel_backward(monkeypatch):
     """The 32-filter cell's groups (48 joint input channels) through the one-launch backward step against the
     pointwise / dgrad / wgrad sequence: every gradient, bf16, partial tiles, a finished and an empty sample."""

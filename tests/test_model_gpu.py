@@ -51,14 +51,16 @@ def rel_err(got, ref):
 
 BF16_GRAD_L2, BF16_GRAD_COS = 3e-1, 0.95  # measured worst: 0.23 and 0.973 (EndTokenDeep_2, first encoder kernel)
 
+# (the reference runs every graph at 28 x 28; the History0 plumbing configuration is named at 32 x 32, where a row of
+# the grid is exactly one 32-pixel tile wide instead of a partial one)
 CASES = [("History2Large", dict()), ("History0", dict()), ("RNNConv", dict()), ("EndTokenDeep_2", dict()),
-         ("History1Large", dict())]
+         ("History1Large", dict()), ("History0", dict(P=32, B=4))]
 
 
 @pytest.mark.parametrize("name,kw", CASES)
 def test_fp32_logits_loss_grads_and_adam_step(name, kw):
     from imagesegmentation_amd.polyrnn import experiments
-    P, B = 28, 3
+    P, B = kw.get("P", 28), kw.get("B", 3)
     rs = np.random.RandomState(len(name))
     model = experiments.make(name, image_size=P, compute_dtype=torch.float32, device="cuda:0")
     hist, T = model.history_length, model.max_timesteps
@@ -92,11 +94,11 @@ def test_fp32_logits_loss_grads_and_adam_step(name, kw):
         assert np.abs(p.detach().double().cpu().numpy() - want).max() < 1e-2 * step + 1e-9
 
 
-@pytest.mark.parametrize("name", ["History2Large", "RNNConv", "EndTokenDeep_2"])
-def test_bf16_model_tracks_the_oracle(name):
+@pytest.mark.parametrize("name,P", [("History2Large", 28), ("RNNConv", 28), ("EndTokenDeep_2", 28), ("History0", 32)])
+def test_bf16_model_tracks_the_oracle(name, P):
     """Documented bf16 tolerance: logits within 5e-2 of the largest logit magnitude; loss within 2e-2."""
     from imagesegmentation_amd.polyrnn import experiments
-    P, B = 28, 4
+    B = 4
     rs = np.random.RandomState(99)
     model = experiments.make(name, image_size=P, compute_dtype=torch.bfloat16, device="cuda:0")
     hist, T = model.history_length, model.max_timesteps
@@ -625,3 +627,32 @@ def test_encoder_weight_images_match_their_documented_layouts():
         want = a.reshape(ks, kxp // 4, 2, 2, 4, 32).permute(0, 1, 2, 5, 3, 4).reshape(ks * (kxp // 4), 64, 8)
         got = ops.conv_in_pack(w)
         assert torch.equal(got, want.to(torch.bfloat16)), (ks, cout)
+
+
+def test_bf16_training_tracks_f32_training_over_200_steps():
+    """History2Large at 28 x 28 trained for 200 steps on a fixed 64-polygon dataset (the same batches, the same
+    initial weights, Adam 1e-3), once in f32 and once in bf16: the bf16 loss curve stays with the f32 one - the
+    mean loss of the last 20 steps within 5 % - and both have learnt (below 70 % of the first steps' loss).
+    (reference polyrnn/Model.py:96-112: the loss and the update this run repeats.)"""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrnn import experiments
+    ds = data.PolygonDataset.synthetic(64, 28, 28, 10, 2, seed=4, shape_mask_fn=oracle_raster.create_shape_mask)
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = experiments.make("History2Large", image_size=28, compute_dtype=dt, device="cuda:0", seed=11,
+                                 learning_rate=1e-3)
+        np.random.seed(123)
+        losses = []
+        for _ in range(200):
+            d, images, pts, t, _ = ds.get_batch_points(16)
+            losses.append(model.train_step(images, d, pts, t))
+        curves[dt] = torch.stack(losses).float().cpu().numpy()
+    f32, bf16 = curves[torch.float32], curves[torch.bfloat16]
+    first, last32, last16 = f32[:5].mean(), f32[-20:].mean(), bf16[-20:].mean()
+    print("loss: first steps %.4f, last 20 steps f32 %.4f bf16 %.4f; largest gap over the run %.4f" %
+          (first, last32, last16, np.abs(f32 - bf16).max()))
+    assert np.isfinite(f32).all() and np.isfinite(bf16).all()
+    assert last32 < 0.7 * first and last16 < 0.7 * first
+    assert abs(last16 - last32) <= 0.05 * last32
+    # step by step the two runs see the same batch: their losses stay within 15 % of each other all the way
+    assert np.abs(f32 - bf16).max() <= 0.15 * f32.max()
