@@ -145,12 +145,14 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
         x = torch.randn([B, P, P, cs], device=dev).to(dt)
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
-        c = torch.randn([B, P, P, F], device=dev)
-        h2, c2 = torch.empty_like(h), torch.empty_like(c)
         # what the forward step keeps for backward: the backward factors where the fused backward step exists, else
-        # the gate activations for the three-kernel backward (four values per channel either way)
+        # the gate activations for the three-kernel backward (four values per channel either way); with the fused
+        # step the cell state is stored as bf16 (as the training step stores it)
         fused = ops.bwd_fused_supported(packed, B, P, P)
         layout = ops.SAVE_FACTORS if fused else ops.SAVE_GATES
+        c_dt = dt if fused and ops.state_bf16_supported(packed, B, P, P) else torch.float32
+        c = torch.randn([B, P, P, F], device=dev).to(c_dt)
+        h2, c2 = torch.empty_like(h), torch.empty_like(c)
         gates = torch.zeros(ops.saved_shape(B, P, P, F, layout), dtype=dt, device=dev)
         dy = torch.empty([B, P, P, F, 4], dtype=dt, device=dev)
         dh = torch.randn([B, P, P, F], device=dev).to(dt)
@@ -165,7 +167,7 @@ def time_kernels(model, batch, dtype_name, reps=5, in_step=None):
         esz = 2 if dt == torch.bfloat16 else 4
         px = B * P * P
         # algorithmic HBM bytes per pixel: every operand read once, every result written once
-        x_b, h_b, c_b, g_b = (cs if hist else c_real) * esz, F * esz, F * 4, 4 * F * esz
+        x_b, h_b, c_b, g_b = (cs if hist else c_real) * esz, F * esz, F * c.element_size(), 4 * F * esz
         kernels = [
             ("cell_fwd", lambda: ops.cell_fwd(x, h, c, packed, h_out=h2, c_out=c2, gates=gates, hist_points=pts,
                                               save_layout=layout), flops,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "isg_convlstm_wgrad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _ll,
                                   _vp, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_bwd_fused_supported": (_int, [_int, _int, _int, _int, _int, _int, _int]),
+    "isg_convlstm_state_bf16_supported": (_int, [_int, _int, _int, _int, _int, _int]),
     "isg_convlstm_bwd_fused_hist_bytes": (_ll, [_int, _int]),
     "isg_convlstm_bwd_fused_hist_begin": (_int, [_vp, _int, _int, _vp]),
     "isg_convlstm_bwd_fused_hist_finish": (_int, [_vp, _int, _int, _int, _int, _vp, _vp]),

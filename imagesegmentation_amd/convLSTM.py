@@ -287,6 +287,18 @@ class SequenceInput:
         return self._buf
 
 
+def _state_dtype(packed, B, H, W, dx_channels=None):
+    """Storage type of a layer's cell state.  A bf16 layer that runs on the fused kernels (the shapes of every net
+    of the reference) keeps it as bf16: the arithmetic of a step stays float and the new state is rounded once,
+    when it is stored - 64 fewer bytes per pixel in the forward step, 32 in the backward step.  The rule does not
+    depend on whether a pass keeps anything for backward, so that training, validation and step-by-step decoding
+    of one model compute the same numbers.  Float layers, and bf16 layers on the three-kernel backward, keep float
+    states."""
+    if ops.bwd_fused_supported(packed, B, H, W, dx_channels) and ops.state_bf16_supported(packed, B, H, W):
+        return torch.bfloat16
+    return torch.float32
+
+
 _ZERO_STATES = {}
 
 
@@ -317,12 +329,6 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     # (ISG_NO_ZERO_STATE=1: the shared zero tensors are read like any state, for A/B runs)
     from_zero = [init_state[l][0] is None and init_state[l][1] is None and not os.environ.get("ISG_NO_ZERO_STATE")
                  for l in range(L)]
-    for l in range(L):
-        c0, h0 = init_state[l]
-        c_init = _zero_state([B, H, W, F], torch.float32, dev) if c0 is None else c0.detach().to(torch.float32).contiguous()
-        h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
-        Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
-        Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=torch.float32, device=dev).unbind(0)))
     # What a layer keeps for backward (next to its states): the backward factors where the fused backward step
     # exists for its shape, else the gate activations for the three-kernel backward.
     # (Layer 0's input gradient has the width of the static features when the input is the tiled form: the fused
@@ -330,6 +336,13 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     dx0 = seq.static.shape[-1] if seq.x_seq is None else None
     layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W, dx0 if l == 0 else None)
                else ops.SAVE_GATES for l in range(L)]
+    cdts = [_state_dtype(packed[l], B, H, W, dx0 if l == 0 else None) for l in range(L)]
+    for l in range(L):
+        c0, h0 = init_state[l]
+        c_init = _zero_state([B, H, W, F], cdts[l], dev) if c0 is None else c0.detach().to(cdts[l]).contiguous()
+        h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
+        Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
+        Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=cdts[l], device=dev).unbind(0)))
     Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, layouts[l]), dtype=dt, device=dev) for l in range(L)] \
         if save else None
     # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
@@ -358,7 +371,9 @@ def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, po
     if pool > 1 and not fused_pool:
         out = ops.avgpool(out, pool)
     if cur == 0:  # no step ran: hand out copies, never the shared zero tensors or the caller's own state
-        final = [(Cs[l][0].clone(), Hs[l][0].clone()) for l in range(L)]
+        # (of the state as it was given, where one was: not of its copy in the kernels' storage type)
+        final = [(Cs[l][0].clone() if init_state[l][0] is None else init_state[l][0].detach().clone(),
+                  Hs[l][0].clone() if init_state[l][1] is None else init_state[l][1].detach().clone()) for l in range(L)]
     else:
         final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
     return out, final, (Hs, Cs, Gs, packed, layouts)
@@ -385,7 +400,9 @@ class RecurrentStepper:
         self.packed = [self._seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
         self._seq.prepare(dt, self.packed[0].cs)
         self.H = [torch.zeros([2, B, H, W, F], dtype=dt, device=dev) for _ in cells]
-        self.C = [torch.zeros([2, B, H, W, F], dtype=torch.float32, device=dev) for _ in cells]
+        # (the cell state in the type the sequence node stores it in: a decode loop repeats a training pass's numbers)
+        self.C = [torch.zeros([2, B, H, W, F], dtype=_state_dtype(self.packed[l], B, H, W, cf if l == 0 else None),
+                              device=dev) for l in range(len(cells))]
         self.out = torch.zeros([B, 1, H, W, F], dtype=dt, device=dev)
         self.cur = 0
         self._stride = H * W * F

@@ -711,12 +711,26 @@ bool pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int poo
            hist >= 0 && hist <= 2 && (long long)B * H * W * Cs * 2 < (1LL << 32);
 }
 
-int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd, const float* bias,
+// the cell state stored as bf16: only the bf16 ping-pong kernels read and write it that way
+bool state_bf16_supported(int Cs, int F, int dtype, int B, int H, int W) {
+    return F == F_ && dtype == ISG_BF16 && (Cs == 16 || Cs == 32 || Cs == 48) && B >= 1 && H >= 1 && W >= 1 &&
+           (long long)B * H * W * (Cs > F_ ? Cs : F_) * 2 < (1LL << 32);
+}
+
+int cell_fwd_impl(const void* x, const void* h_prev, const void* c_prev_v, const void* packed_fwd, const float* bias,
                   int B, int H, int W, int Cs, int F, int dtype, const int32_t* durations, int t,
                   const int32_t* hist_points, int hist, long long hist_batch_stride, const float* hist_table,
-                  void* h_out, float* c_out, void* out, long long out_batch_stride, void* gates, int save_layout,
+                  void* h_out, void* c_out_v, void* out, long long out_batch_stride, void* gates, int save_layout,
                   void* pool_out, long long pool_batch_stride, void* stream) {
+    const bool state_bf16 = (save_layout & ISG_STATE_BF16) != 0;
+    save_layout &= ~ISG_STATE_BF16;
+    // (typed as float in the kernels' parameter block; the bf16 instantiations cast it back)
+    const float* c_prev = static_cast<const float*>(c_prev_v);
+    float* c_out = static_cast<float*>(c_out_v);
     ISG_REQUIRE(F == F_, ISG_EINVAL, "isg_convlstm: filters must be %d (got %d)", F_, F);
+    ISG_REQUIRE(!state_bf16 || state_bf16_supported(Cs, F, dtype, B, H, W), ISG_EINVAL,
+                "isg_convlstm_cell_fwd: ISG_STATE_BF16 needs bf16 activations and Cs 16, 32 or 48 (got Cs=%d dtype=%d): "
+                "ask isg_convlstm_state_bf16_supported first", Cs, dtype);
     ISG_REQUIRE(x && packed_fwd && bias && h_out && c_out, ISG_EINVAL, "isg_convlstm_cell_fwd: null pointer");
     ISG_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), ISG_EINVAL,
                 "isg_convlstm_cell_fwd: h_prev and c_prev are both given or both NULL (the zero state)");
@@ -736,6 +750,7 @@ int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const 
     p.tiles_x = (W + TW - 1) / TW, p.tiles_y = (H + TH - 1) / TH;
     p.durations = durations, p.t = t;
     p.bias = bias, p.c_prev = c_prev, p.c_out = c_out, p.h_out = h_out, p.out = out;
+    p.state_bf16 = state_bf16 ? 1 : 0;
     p.out_bstride = out_batch_stride, p.gates = gates;
     p.pool_out = pool_out, p.pool_bstride = pool_batch_stride;
     p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_table = hist_table;
@@ -747,15 +762,20 @@ int cell_fwd_impl(const void* x, const void* h_prev, const float* c_prev, const 
     p.spt = (Cs + F_) / 16;
     rc = launch_conv_pp(p, 2, 0, num_cus(), s);
     if (rc != kNotSupported) return rc;
+    ISG_REQUIRE(!state_bf16, ISG_EINVAL, "isg_convlstm_cell_fwd: no kernel with a bf16 cell state for this shape");
     ISG_REQUIRE(pool_out == nullptr, ISG_EINVAL, "isg_convlstm_cell_fwd_pooled: no kernel with a pooled output for this shape");
     return launch_conv<__bf16, 2, 0>(p, s);
 }
 }  // namespace
 
-extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+extern "C" int isg_convlstm_state_bf16_supported(int Cs, int F, int dtype, int B, int H, int W) {
+    return state_bf16_supported(Cs, F, dtype, B, H, W) ? 1 : 0;
+}
+
+extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const void* c_prev, const void* packed_fwd,
                                      const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                                      const int32_t* durations, int t, const int32_t* hist_points, int hist,
-                                     long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
+                                     long long hist_batch_stride, const float* hist_table, void* h_out, void* c_out,
                                      void* out, long long out_batch_stride, void* gates, int save_layout,
                                      void* stream) {
     return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
@@ -767,11 +787,11 @@ extern "C" int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B
     return pooled_fwd_supported(Cs, F, dtype, B, H, W, pool, hist) ? 1 : 0;
 }
 
-extern "C" int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const float* c_prev,
+extern "C" int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const void* c_prev,
                                             const void* packed_fwd, const float* bias, int B, int H, int W, int Cs,
                                             int F, int dtype, const int32_t* durations, int t,
                                             const int32_t* hist_points, int hist, long long hist_batch_stride,
-                                            const float* hist_table, void* h_out, float* c_out, void* gates,
+                                            const float* hist_table, void* h_out, void* c_out, void* gates,
                                             int save_layout, int pool, void* pool_out, long long pool_batch_stride,
                                             void* stream) {
     ISG_REQUIRE(pool_out, ISG_EINVAL, "isg_convlstm_cell_fwd_pooled: null pooled output");

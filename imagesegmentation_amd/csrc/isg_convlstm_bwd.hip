@@ -55,7 +55,8 @@ __device__ __forceinline__ unsigned long long bwd_stamp() {
 
 struct BwdParams {
     const void* gates;      // backward factors [B,H,W,F/2,4,2] bf16 (A, B, f, o of lstm_backward_factors)
-    const float* c_prev;    // [B,H,W,F]
+    const float* c_prev;    // [B,H,W,F] float, or bf16 when cprev_bf16
+    int cprev_bf16;
     const void* h_cur;      // [B,H,W,F]: this step's new h
     const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
     long long dh_above_bstride;
@@ -152,7 +153,8 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 // 2 - 4 %: a dozen more spilled scalar registers in the tile loop).  Bit 0: no gradient is carried in (dh_state and
 // dc_state null: the first step of the reverse sweep when the final state is not differentiated); bit 1: the step
 // out of the zero state (c_prev and h_prev null).  Nothing is read for a null operand; zeros take its place.
-template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD = false>
+// CB: c_prev is stored as bf16 (a forward pass run with ISG_STATE_BF16): 8 instead of 16 bytes per item.
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD = false, bool CB = false>
 __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdParams p) {
     constexpr bool no_carry = (EDGE & 1) != 0, zero_state = (EDGE & 2) != 0;
     using K = FB<C0, MT, TR, PIPE, HOLD>;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
 
     // ---- staged operands of one tile ----
     uint4 sg[K::NPW][2];             // factors of the item's two channel pairs: A A B B f f o o
-    uint4 scp[K::NPW];               // c_prev: 4 floats
+    std::conditional_t<CB, uint2, uint4> scp[K::NPW];  // c_prev: 4 floats, or 4 bf16
     uint2 shc[K::NPW];               // this step's h: 4 bf16
     uint2 sda[K::NPW], sds[K::NPW], sdc[K::NPW];  // dh_above, dh_state, dc_state: 4 bf16
     uint4 sx[K::NXP];
@@ -292,8 +294,13 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         const unsigned pixel = (unsigned)(r.b * p.H) * (unsigned)p.W + pix;
         sg[j][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u));
         sg[j][1] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.gates) + (size_t)(pixel * 128u + q * 32u + 16u));
-        if constexpr (zero_state) scp[j] = make_uint4(0u, 0u, 0u, 0u);
-        else scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
+        if constexpr (CB) {
+            if constexpr (zero_state) scp[j] = make_uint2(0u, 0u);
+            else scp[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 32u + q * 8u));
+        } else {
+            if constexpr (zero_state) scp[j] = make_uint4(0u, 0u, 0u, 0u);
+            else scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
+        }
         shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * 32u + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
@@ -414,8 +421,13 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         // word 4 (ch >> 1) + k holds value k (A, B, f, o) of channels ch & ~1 (low half) and ch | 1 (high)
                         const unsigned fw[8] = {sg[j][0].x, sg[j][0].y, sg[j][0].z, sg[j][0].w,
                                                 sg[j][1].x, sg[j][1].y, sg[j][1].z, sg[j][1].w};
-                        const float cpv[4] = {__uint_as_float(scp[j].x), __uint_as_float(scp[j].y), __uint_as_float(scp[j].z),
-                                              __uint_as_float(scp[j].w)};
+                        float cpv[4];
+                        if constexpr (CB) {
+                            cpv[0] = bf_lo(scp[j].x), cpv[1] = bf_hi(scp[j].x), cpv[2] = bf_lo(scp[j].y), cpv[3] = bf_hi(scp[j].y);
+                        } else {
+                            cpv[0] = __uint_as_float(scp[j].x), cpv[1] = __uint_as_float(scp[j].y);
+                            cpv[2] = __uint_as_float(scp[j].z), cpv[3] = __uint_as_float(scp[j].w);
+                        }
                         const float hv[4] = {bf_lo(shc[j].x), bf_hi(shc[j].x), bf_lo(shc[j].y), bf_hi(shc[j].y)};
                         const float da[4] = {bf_lo(sda[j].x), bf_hi(sda[j].x), bf_lo(sda[j].y), bf_hi(sda[j].y)};
                         const float ds[4] = {bf_lo(sds[j].x), bf_hi(sds[j].x), bf_lo(sds[j].y), bf_hi(sds[j].y)};
@@ -1044,19 +1056,22 @@ __global__ __launch_bounds__(NG) void hist_side_finish_kernel(const float* __res
     *dst = accumulate ? *dst + sum : sum;
 }
 
-template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD>
+template <int C0, int MT, int TR, bool PIPE, bool ACC, int EDGE, bool HOLD, bool CB = false>
 int launch_bwd_edge(BwdParams p, hipStream_t stream) {
     using K = FB<C0, MT, TR, PIPE, HOLD>;
+    if constexpr (!CB) {  // c_prev stored as bf16: instantiations of their own
+        if (p.cprev_bf16) return launch_bwd_edge<C0, MT, TR, PIPE, ACC, EDGE, HOLD, true>(p, stream);
+    }
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TR - 1) / TR;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD, CB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one slab per workgroup, as many as isg_convlstm_wgrad_finish folds: its count goes by 8-row tiles
     const int ntiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
     const int grid = ntiles8 < kWgradMaxBlocks ? ntiles8 : kWgradMaxBlocks;
-    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD>), dim3(grid), dim3(kBwdThreads), K::LDS_BYTES, stream,
-                       p);
+    hipLaunchKernelGGL((convlstm_bwd_fused_kernel<C0, MT, TR, PIPE, ACC, EDGE, HOLD, CB>), dim3(grid), dim3(kBwdThreads),
+                       K::LDS_BYTES, stream, p);
     return isg::check_launch("convlstm_bwd_fused_kernel");
 }
 
@@ -1111,7 +1126,7 @@ extern "C" long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist) {
     return hist_dy_bytes(B, hist) + (long long)kHistGroups * 9 * hist * NG * 4;
 }
 
-extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, const void* h_cur, const void* dh_above,
+extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev_v, const void* h_cur, const void* dh_above,
                                       long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
                                       const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
                                       int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
@@ -1121,7 +1136,9 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
                                       void* stream) {
     // (ISG_HIST_DEFER: the caller zeroes the history scratch once and folds it once, see isg_convlstm_bwd_fused_hist_finish)
     const bool hist_defer = (mode & ISG_HIST_DEFER) != 0;
-    mode &= ~ISG_HIST_DEFER;
+    const bool cprev_bf16 = (mode & ISG_CPREV_BF16) != 0;
+    mode &= ~(ISG_HIST_DEFER | ISG_CPREV_BF16);
+    const float* c_prev = static_cast<const float*>(c_prev_v);  // (typed as float in the parameter block)
     ISG_REQUIRE(bwd_supported(Cs, F, dtype, B, H, W, hist), ISG_EINVAL,
                 "isg_convlstm_bwd_fused: needs bf16, F = 16, Cs 16, 32 or 48, hist <= 2 (got Cs=%d F=%d dtype=%d hist=%d): ask "
                 "isg_convlstm_bwd_fused_supported first", Cs, F, dtype, hist);
@@ -1153,7 +1170,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const float* c_prev, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int MT = (Cs + F_ + 31) / 32;
     BwdParams p = {};
-    p.gates = gates, p.c_prev = c_prev, p.h_cur = h_cur;
+    p.gates = gates, p.c_prev = c_prev, p.cprev_bf16 = cprev_bf16 ? 1 : 0, p.h_cur = h_cur;
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
     p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
     p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;

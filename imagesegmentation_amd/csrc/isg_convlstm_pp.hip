@@ -87,7 +87,12 @@ struct PP {
 // ZS (forward only): the step out of the zero state - in1 (h_prev) and c_prev are null, nothing is read for them and
 // zeros take their place.  An instantiation of its own: as run-time facts the few extra scalars spilled a dozen more
 // scalar registers in the loops of every launch (+2 - 7 % per launch).
-template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false>
+// CB (forward only): the cell state (c_prev in, c_out out) is stored as bf16 instead of float - 64 fewer bytes per
+// pixel of a launch that runs at the memory system's pace.  The arithmetic stays float; c is rounded once per step.
+// SF (forward only): what the step keeps for backward is the backward factors (ISG_SAVE_FACTORS), else the gate
+// activations - a compile-time fact: as a run-time one it cost seven selects per channel pair in the finish phase,
+// which is bound by the vector ALU.
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false, bool CB = false, bool SF = false>
 __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     using K = PP<C0, C1, MT, MODE, NPT>;
     using T = __bf16;
@@ -292,6 +297,8 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             if constexpr (MODE == 0) {
                 if constexpr (ZS) {
                     pre[2 * pt] = pre[2 * pt + 1] = make_uint4(0u, 0u, 0u, 0u);  // 0.0f: the zero cell state
+                } else if constexpr (CB) {
+                    pre[2 * pt] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.c_prev) + pixel * F_ + 8 * half);
                 } else {
                     const uint4* src = reinterpret_cast<const uint4*>(p.c_prev + pixel * F_ + 8 * half);
                     pre[2 * pt] = src[0];
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
     auto epilogue = [&](const TileRef& r) {
         if (!r.valid) return;
         if (!r.live) {
-            if constexpr (MODE == 0) lstm_copy_through_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
+            if constexpr (MODE == 0) lstm_copy_through_tile<T, std::conditional_t<CB, T, float>>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             else dgrad_zero_dx_tile<T>(p, r.b, r.ty0, r.tx0, gtid, 256, K::TH_);
             return;
         }
@@ -338,6 +345,12 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                               hpx[i] <= r.tx0 + TW;
         }
         float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's channels summed over its rows
+        // Two copies of the per-pixel code: the (rare) wave near a history point adds the taps to its pre-activations,
+        // every other wave runs a copy without that code - under a run-time test inside one copy, every channel of
+        // every wave first copied its four pre-activations (4 of ~80 vector instructions per channel and pixel in
+        // a phase bound by the vector ALU).
+        auto pixels = [&](auto np_c) __attribute__((always_inline)) {
+        constexpr bool NP = decltype(np_c)::value;
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int gy = r.ty0 + NPT * wave + pt, gx = r.tx0 + px_l;
@@ -347,11 +360,19 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                 // state; gate activations leave as 16-byte stores every second channel
                 const size_t pixel = ((size_t)r.b * p.H + gy) * p.W + gx;
                 const size_t so = pixel * F_ + 8 * half;
-                const float cp[8] = {__uint_as_float(pre[2 * pt].x),     __uint_as_float(pre[2 * pt].y),
-                                     __uint_as_float(pre[2 * pt].z),     __uint_as_float(pre[2 * pt].w),
-                                     __uint_as_float(pre[2 * pt + 1].x), __uint_as_float(pre[2 * pt + 1].y),
-                                     __uint_as_float(pre[2 * pt + 1].z), __uint_as_float(pre[2 * pt + 1].w)};
-                const bool factors = p.save_layout == ISG_SAVE_FACTORS;
+                float cp[8];
+                if constexpr (CB && !ZS) {  // eight bf16 values: the low and the high half of each word
+                    const unsigned w[4] = {pre[2 * pt].x, pre[2 * pt].y, pre[2 * pt].z, pre[2 * pt].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        cp[2 * k] = __uint_as_float(w[k] << 16), cp[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+                } else {
+                    const unsigned w[8] = {pre[2 * pt].x,     pre[2 * pt].y,     pre[2 * pt].z,     pre[2 * pt].w,
+                                           pre[2 * pt + 1].x, pre[2 * pt + 1].y, pre[2 * pt + 1].z, pre[2 * pt + 1].w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cp[k] = __uint_as_float(w[k]);
+                }
+                constexpr bool factors = SF;
                 T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
                 float hn[8], cn[8], gprev[4];
 #pragma unroll
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                         const int cl = 4 * t + a4;
                         float z[4] = {acc[t][pt][4 * a4], acc[t][pt][4 * a4 + 1], acc[t][pt][4 * a4 + 2],
                                       acc[t][pt][4 * a4 + 3]};
-                        if (near_point) {
+                        if constexpr (NP) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const int ty = hpy[i] - gy + 1, tx = hpx[i] - gx + 1;
@@ -392,8 +413,12 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                             gprev[0] = s0, gprev[1] = s1, gprev[2] = fg, gprev[3] = og;
                         }
                     }
-                *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
-                *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
+                if constexpr (CB) {
+                    store8(reinterpret_cast<T*>(p.c_out) + so, cn);
+                } else {
+                    *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+                    *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
+                }
                 store8(static_cast<T*>(p.h_out) + so, hn);
                 if (p.out)
                     store8(static_cast<T*>(p.out) + (size_t)r.b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
@@ -420,6 +445,13 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                         }
                     }
             }
+        }
+        };
+        if constexpr (MODE == 0) {
+            if (near_point) pixels(std::true_type{});
+            else pixels(std::false_type{});
+        } else {
+            pixels(std::false_type{});
         }
         if constexpr (MODE == 0) {
             if (p.pool_out) {
@@ -551,11 +583,17 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
 #endif
 }
 
-template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false>
+template <int C0, int C1, int MT, int MODE, bool EARLY, int NPT = 2, bool ZS = false, bool CB = false, bool SF = false>
 int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     using K = PP<C0, C1, MT, MODE, NPT>;
+    if constexpr (MODE == 0 && !SF) {  // what is kept for backward: instantiations of their own
+        if (p0.save_layout == ISG_SAVE_FACTORS) return launch_pp<C0, C1, MT, MODE, EARLY, NPT, ZS, CB, true>(p0, num_cus, stream);
+    }
+    if constexpr (MODE == 0 && !CB) {  // the cell state stored as bf16: instantiations of their own
+        if (p0.state_bf16) return launch_pp<C0, C1, MT, MODE, EARLY, NPT, ZS, true, SF>(p0, num_cus, stream);
+    }
     if constexpr (MODE == 0 && !ZS) {  // the step out of the zero state has an instantiation of its own
-        if (p0.in1 == nullptr) return launch_pp<C0, C1, MT, MODE, EARLY, NPT, true>(p0, num_cus, stream);
+        if (p0.in1 == nullptr) return launch_pp<C0, C1, MT, MODE, EARLY, NPT, true, CB, SF>(p0, num_cus, stream);
     }
     static_assert(K::LDS_BYTES <= 160 * 1024, "ping-pong LDS budget");
     if (MODE == 0 && p0.hist > 2) return kNotSupported;
@@ -564,14 +602,14 @@ int launch_pp(const ConvParams& p0, int num_cus, hipStream_t stream) {
     if ((long long)p0.B * p0.H * p0.W * (C0 > C1 ? C0 : C1) * 2 >= (1LL << 32)) return kNotSupported;
     ConvParams p = p0;
     p.tiles_y = (p.H + K::TH_ - 1) / K::TH_;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS, CB, SF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     ISG_REQUIRE(e == hipSuccess, ISG_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int ntiles = p.tiles_x * p.tiles_y * p.B;
     const int pairs = (ntiles + 1) / 2;
     const int grid = pairs < num_cus ? pairs : num_cus;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES, stream,
-                       p);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<C0, C1, MT, MODE, EARLY, NPT, ZS, CB, SF>), dim3(grid), dim3(kPPThreads), K::LDS_BYTES,
+                       stream, p);
     return isg::check_launch("conv3x3_pp_kernel");
 }
 

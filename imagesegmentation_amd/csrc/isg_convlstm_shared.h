@@ -101,6 +101,7 @@ struct ConvParams {
     const float* bias;     // [4F] reference order
     const float* c_prev;   // [B,H,W,F]
     float* c_out;          // [B,H,W,F]
+    int state_bf16;        // c_prev / c_out hold bf16 instead of float (bf16 ping-pong kernels only)
     void* h_out;           // [B,H,W,F]
     void* out;             // masked output or null; sample stride out_bstride elements
     long long out_bstride;
@@ -269,8 +270,8 @@ __device__ __forceinline__ void lstm_finish_pixel(const ConvParams& p, int b, in
 }
 
 // dynamic_rnn past the end of a sequence: the state of the tile's pixels is copied through and the
-// emitted output is zero.  Called by `nthreads` threads with ids 0..nthreads-1.
-template <typename T>
+// emitted output is zero.  Called by `nthreads` threads with ids 0..nthreads-1.  CT: the cell state's type.
+template <typename T, typename CT = float>
 __device__ __forceinline__ void lstm_copy_through_tile(const ConvParams& p, int b, int ty0, int tx0, int tid,
                                                        int nthreads, int tile_rows = TH) {
     for (int i = tid; i < tile_rows * TW * (F_ / 4); i += nthreads) {
@@ -280,12 +281,12 @@ __device__ __forceinline__ void lstm_copy_through_tile(const ConvParams& p, int 
             const size_t pixel = ((size_t)b * p.H + gy) * p.W + gx;
             const size_t o = pixel * F_ + q4 * 4;
             float hv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            f32x4 cv = {0.0f, 0.0f, 0.0f, 0.0f};
+            float cv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (p.c_prev) {  // (null: the zero state passes through as zeros)
-                cv = *reinterpret_cast<const f32x4*>(p.c_prev + o);
+                load4(reinterpret_cast<const CT*>(p.c_prev) + o, cv);
                 load4(static_cast<const T*>(p.in1) + o, hv);
             }
-            *reinterpret_cast<f32x4*>(p.c_out + o) = cv;
+            store4(reinterpret_cast<CT*>(p.c_out) + o, cv);
             store4(static_cast<T*>(p.h_out) + o, hv);
             if (p.out) {
                 const float zero[4] = {0.f, 0.f, 0.f, 0.f};

@@ -189,6 +189,17 @@ def pooled_fwd_supported(packed, B, H, W, pool):
 
 
 SAVE_GATES, SAVE_FACTORS = 0, 1  # what a forward step keeps for the backward pass (ISG_SAVE_* of include/isg.h)
+STATE_BF16 = 0x10                # or-ed into the save layout: c_prev / c_out hold bf16 (ISG_STATE_BF16)
+CPREV_BF16 = 0x200               # or-ed into bwd_fused's mode: c_prev holds bf16 (ISG_CPREV_BF16)
+
+
+def state_bf16_supported(packed, B, H, W):
+    """Whether the forward step can keep the cell state in bf16 for this cell shape (the bf16 ping-pong kernels;
+    ISG_STATE_F32=1 answers no: float cell states everywhere, for A/B runs)."""
+    if os.environ.get("ISG_STATE_F32"):
+        return False
+    return bool(_lib.lib().isg_convlstm_state_bf16_supported(packed.cs, packed.f, dtype_code(packed.dtype), int(B),
+                                                             int(H), int(W)))
 
 
 def saved_shape(B, H, W, F, layout):
@@ -202,7 +213,9 @@ def saved_shape(B, H, W, F, layout):
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
              h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1,
              save_layout=SAVE_GATES):
-    """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32.
+    """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32 - or bfloat16, which
+    makes the step read and write the cell state as bfloat16 (where ``state_bf16_supported``; ``c_out`` then
+    decides when c_prev is None).
     h_prev = c_prev = None: the zero state.
     hist_points: int32 [B,hist,2] when the packed weights carry history channels.
     ``gates`` (or ``save_gates``): the buffer kept for backward, in ``save_layout`` (see ``saved_shape``).
@@ -214,11 +227,16 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     F = packed.f
     assert Cs == packed.cs and x.dtype == packed.dtype
     assert (h_prev is None) == (c_prev is None)  # both None: the zero state, nothing is read for it
-    assert h_prev is None or (h_prev.dtype == packed.dtype and c_prev.dtype == torch.float32)
+    cdt = c_prev.dtype if c_prev is not None else (c_out.dtype if c_out is not None else torch.float32)
+    assert h_prev is None or h_prev.dtype == packed.dtype
+    assert cdt == torch.float32 or (cdt == torch.bfloat16 and x.dtype == torch.bfloat16)
     h = torch.empty([B, H, W, F], dtype=x.dtype, device=x.device) if h_out is None else h_out
-    c = torch.empty([B, H, W, F], dtype=torch.float32, device=x.device) if c_out is None else c_out
+    c = torch.empty([B, H, W, F], dtype=cdt, device=x.device) if c_out is None else c_out
+    assert c.dtype == cdt, "the cell state before and after a step is stored in one type"
+    if cdt == torch.bfloat16:
+        save_layout = int(save_layout) | STATE_BF16
     if gates is None and save_gates:
-        gates = torch.empty(saved_shape(B, H, W, F, save_layout), dtype=x.dtype, device=x.device)
+        gates = torch.empty(saved_shape(B, H, W, F, save_layout & ~STATE_BF16), dtype=x.dtype, device=x.device)
     assert gates is None or (gates.is_contiguous() and gates.numel() == B * H * W * F * 4)
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     if pool_out is not None:
@@ -373,7 +391,9 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
     B, H, W, F = h_cur.shape
     gates = factors
     assert factors.is_contiguous() and factors.numel() == B * H * W * F * 4 and factors.dtype == torch.bfloat16
-    assert (c_prev is None or c_prev.dtype == torch.float32) and h_cur.dtype == torch.bfloat16
+    assert (c_prev is None or c_prev.dtype in (torch.float32, torch.bfloat16)) and h_cur.dtype == torch.bfloat16
+    if c_prev is not None and c_prev.dtype == torch.bfloat16:
+        mode = int(mode) | CPREV_BF16
     pts, pts_stride = _points_arg(hist_points, packed.hist)
     scratch = None
     scratch_ptr = None

@@ -159,10 +159,18 @@ int isg_convlstm_pack_weights(const float* w_x, const float* w_h, int C, int Cs,
  * hist_points: int32 (x, y) pairs of this step's frames, sample b at hist_points + b*hist_batch_stride,
  * x < 0 = empty frame. */
 enum { ISG_SAVE_GATES = 0, ISG_SAVE_FACTORS = 1 };
-int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+/* save_layout | ISG_STATE_BF16: c_prev and c_out hold bf16 instead of float (the arithmetic stays float; the new
+ * cell state is rounded once, when it is stored): 64 fewer bytes per pixel of a step that runs at the memory
+ * system's pace.  Only where isg_convlstm_state_bf16_supported(...) returns 1 (bf16 activations, Cs 16, 32 or 48:
+ * the shapes the ping-pong kernels take).  The reference keeps the cell state in float
+ * (convLSTM.py:42); what this costs in accuracy is bounded in tests/ (bf16 tolerance, 200-step training curve).
+ * isg_convlstm_bwd_fused takes such a c_prev with mode | ISG_CPREV_BF16. */
+enum { ISG_STATE_BF16 = 0x10 };
+int isg_convlstm_state_bf16_supported(int Cs, int F, int dtype, int B, int H, int W);
+int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const void* c_prev, const void* packed_fwd,
                           const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                           const int32_t* durations, int t, const int32_t* hist_points, int hist,
-                          long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out, void* out,
+                          long long hist_batch_stride, const float* hist_table, void* h_out, void* c_out, void* out,
                           long long out_batch_stride, void* gates, int save_layout, void* stream);
 
 /* The same step for a caller that only wants the emitted output AVERAGED over pool x pool windows (the head on
@@ -172,10 +180,10 @@ int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const float* c_prev
  * Only where isg_convlstm_pooled_fwd_supported(...) returns 1 (bf16, Cs 16 or 32, pool 8, H % 8 == 0,
  * W % 32 == 0); otherwise use isg_convlstm_cell_fwd + isg_avgpool_fwd. */
 int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist);
-int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const float* c_prev, const void* packed_fwd,
+int isg_convlstm_cell_fwd_pooled(const void* x, const void* h_prev, const void* c_prev, const void* packed_fwd,
                                  const float* bias, int B, int H, int W, int Cs, int F, int dtype,
                                  const int32_t* durations, int t, const int32_t* hist_points, int hist,
-                                 long long hist_batch_stride, const float* hist_table, void* h_out, float* c_out,
+                                 long long hist_batch_stride, const float* hist_table, void* h_out, void* c_out,
                                  void* gates, int save_layout, int pool, void* pool_out, long long pool_batch_stride,
                                  void* stream);
 
@@ -252,11 +260,11 @@ int isg_convlstm_wgrad_finish(const void* workspace, int B, int H, int W, int C,
  *   replaces. */
 int isg_convlstm_bwd_fused_supported(int Cs, int F, int dtype, int B, int H, int W, int hist);
 long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist);
-enum { ISG_HIST_DEFER = 0x100 };
+enum { ISG_HIST_DEFER = 0x100, ISG_CPREV_BF16 = 0x200 };  /* mode | ISG_CPREV_BF16: c_prev holds bf16 (see ISG_STATE_BF16) */
 int isg_convlstm_bwd_fused_hist_begin(void* hist_scratch, int samples, int hist, void* stream);
 int isg_convlstm_bwd_fused_hist_finish(void* hist_scratch, int samples, int hist, int C, int accumulate, float* dw_x,
                                        void* stream);
-int isg_convlstm_bwd_fused(const void* factors, const float* c_prev, const void* h_cur, const void* dh_above,
+int isg_convlstm_bwd_fused(const void* factors, const void* c_prev, const void* h_cur, const void* dh_above,
                            long long dh_above_batch_stride, int dh_above_pool, const void* dh_state, const void* dc_state, const void* x,
                            const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs, int F,
                            int dtype, const int32_t* durations, int t,

@@ -803,3 +803,59 @@ def test_first_step_out_of_the_zero_state_reads_no_state(dtype, final_in_loss, m
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert float(got[0][1].abs().max()) == 0.0 and float(got[2][1].abs().max()) == 0.0   # the empty sample: zeros
+
+
+@pytest.mark.parametrize("cs,hist,shape", [(32, 1, (3, 16, 64)), (16, 0, (2, 19, 37)), (48, 0, (2, 12, 40))])
+def test_bf16_cell_state_is_the_float_state_rounded_once(cs, hist, shape):
+    """ISG_STATE_BF16 / ISG_CPREV_BF16: a step that reads and writes the cell state as bf16 computes in float like the
+    float-state step - given the same (bf16-representable) c_prev its h, its saved factors and its pooled output are
+    bit-identical, and its c_out is the float-state c_out rounded to bf16; a finished sample's state passes
+    through; the step out of the zero state writes bf16 too.  The fused backward step reading that c_prev as bf16
+    gives bit-identical gradients."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell
+    dt, d = torch.bfloat16, dev()
+    B, H, W = shape
+    g = torch.Generator(device=d).manual_seed(cs + hist)
+    cell = ConvLSTMCell([H, W], 16, [3, 3], compute_dtype=dt, device=d).build(cs + hist, d)
+    packed = cell.packed(hist=hist)
+    assert ops.state_bf16_supported(packed, B, H, W)
+    x = torch.randn([B, H, W, cs], device=d, generator=g).to(dt)
+    h = (torch.randn([B, H, W, 16], device=d, generator=g) * 0.5).to(dt)
+    c16 = (torch.randn([B, H, W, 16], device=d, generator=g) * 1.5).to(dt)
+    c32 = c16.float()
+    pts = torch.randint(0, min(H, W), [B, hist, 2], device=d, generator=g, dtype=torch.int32) if hist else None
+    dur = torch.tensor([3, 1, 2][:B], dtype=torch.int32, device=d)  # sample 1 is finished at t = 1
+    ha, ca, fa = ops.cell_fwd(x, h, c32, packed, dur, 1, hist_points=pts, save_layout=ops.SAVE_FACTORS)
+    hb, cb, fb = ops.cell_fwd(x, h, c16, packed, dur, 1, hist_points=pts, save_layout=ops.SAVE_FACTORS)
+    assert ca.dtype == torch.float32 and cb.dtype == torch.bfloat16
+    assert torch.equal(ha, hb)
+    assert torch.equal(ca.to(dt), cb)
+    live = [b for b in range(B) if int(dur[b]) > 1]  # (nothing is saved for a finished sample)
+    assert torch.equal(fa[live], fb[live])
+    assert torch.equal(cb[1], c16[1]) and torch.equal(hb[1], h[1])
+    # out of the zero state
+    hz32, cz32, _ = ops.cell_fwd(x, None, None, packed, None, 0, hist_points=pts, save_gates=False)
+    cz = torch.empty([B, H, W, 16], dtype=dt, device=d)
+    hz16, cz16, _ = ops.cell_fwd(x, None, None, packed, None, 0, hist_points=pts, save_gates=False, c_out=cz)
+    assert cz16.dtype == dt and torch.equal(hz32, hz16) and torch.equal(cz32.to(dt), cz16)
+    # the fused backward step on the bf16 c_prev
+    rnd = lambda *s: torch.randn(list(s), device=d, generator=g)
+    above, dh, dc = rnd(B, H, W, 16).to(dt), rnd(B, H, W, 16).to(dt), rnd(B, H, W, 16).to(dt)
+    outs = []
+    for c_prev in (c32, c16):
+        dc2, dh2 = torch.empty_like(dc), torch.empty_like(dh)
+        dx = torch.zeros([B, H, W, cs], dtype=dt, device=d)
+        ws = ops.wgrad_workspace(cs, 16, d, cached=False)
+        dwx = torch.zeros_like(cell.input_to_state_kernel)
+        dwh, db = torch.zeros_like(cell.hidden_to_state_kernel), torch.zeros_like(cell.bias)
+        ops.bwd_fused(fa, c_prev, ha, above, H * W * 16, dh, dc, x, h, packed, dc2, dh2, ws, ops.WGRAD_DEFER_FIRST, dwx,
+                      dx=dx, dx_channels=cs, durations=dur, t=1, hist_points=pts)
+        ops.wgrad_finish(ws, (B, H, W, cs), packed.c, hist, dwx, dwh, db)
+        outs.append((dc2, dh2, dx, dwx, dwh, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and the flag is refused where no kernel stores the state that way
+    x32 = torch.randn([B, H, W, 16], device=d)
+    c4 = ConvLSTMCell([H, W], 16, [3, 3], compute_dtype=torch.float32, device=d).build(16, d)
+    assert not ops.state_bf16_supported(c4.packed(), B, H, W)

@@ -176,7 +176,9 @@ def test_fused_backward_matches_the_three_kernel_backward_at_full_size(with_init
     ref, n_ref = _sweep(multi, feat, pts, durations, d_out, False, monkeypatch, init)
     got, n_got = _sweep(multi, feat, pts, durations, d_out, True, monkeypatch, init)
     assert n_ref == 0 and n_got == 2 * 5
-    assert torch.equal(got["out"], ref["out"])  # the forward pass does not depend on what is saved for backward
+    # (the forward passes differ only in how the cell state is stored: bf16 beside the fused step, float beside the
+    # three-kernel backward - one bf16 rounding of c per step)
+    assert float((got["out"].float() - ref["out"].float()).abs().max()) <= 2e-2 * float(ref["out"].float().abs().max())
     for key in ref:
         a, b = got[key].float(), ref[key].float()
         scale = max(float(b.abs().max()), 1e-6)
