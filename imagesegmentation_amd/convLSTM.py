@@ -533,11 +533,19 @@ class _SequenceFunction(torch.autograd.Function):
         grads = []
         # (every entry is assigned by the sweep - the history taps' rows by its first step, the rest by the closing
         # fold of the partial sums - so only a sweep of no steps needs the zeros)
+        # A parameter with a gradient sink (ops.grad_sinks: a view of the trainer's flat gradient buffer) gets its
+        # gradient written there by the sweep's kernels, and autograd gets None for it.
         like = torch.empty_like if t_run > 0 else torch.zeros_like
+        sunk = []
         for cell in cells:
-            grads.append((like(cell.input_to_state_kernel, dtype=torch.float32),
-                          like(cell.hidden_to_state_kernel, dtype=torch.float32),
-                          like(cell.bias, dtype=torch.float32)))
+            params = (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias)
+            dsts = [ops.grad_destination(prm) for prm in params]
+            sunk.append([d is not None for d in dsts])
+            if t_run == 0:
+                for d in dsts:
+                    if d is not None:
+                        d.zero_()
+            grads.append(tuple(d if d is not None else like(prm, dtype=torch.float32) for d, prm in zip(dsts, params)))
         dy = torch.empty([B, H, W, F, 4], dtype=dt, device=dev)
         dx_mid = torch.empty([B, H, W, F], dtype=dt, device=dev)
         cs0 = packed[0].cs
@@ -613,7 +621,13 @@ class _SequenceFunction(torch.autograd.Function):
             cd, hd = ctx.state_dtypes[l]
             result += [None if cd is None else dc_state[l].to(cd), None if hd is None else dh_state[l].to(hd)]
         for l in range(L):
-            result += list(grads[l])
+            params = (cells[l].input_to_state_kernel, cells[l].hidden_to_state_kernel, cells[l].bias)
+            for k in range(3):
+                if sunk[l][k]:
+                    ops.grad_delivered(params[k])
+                    result.append(None)
+                else:
+                    result.append(grads[l][k])
         # The returned final states are entries of the saved buffers, whose grad_fn is this node: a reference cycle
         # through ctx.saved that only the garbage collector would break, gigabytes at a time.  Nothing runs
         # backward through this node twice.

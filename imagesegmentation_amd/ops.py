@@ -65,6 +65,53 @@ def adam_tf_(param, m, v, grad, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_nor
     _weights_epoch += 1
 
 
+# ---- gradient sinks ------------------------------------------------------------------------------------
+# A trainer that owns one flat gradient buffer (polyrnn Model, optim.FlatAdam users) can name, per parameter, the
+# view of that buffer the gradient belongs in.  The hand-written backward passes then write there themselves and
+# hand autograd ``None`` for the parameter: no gradient tensor of its own, no AccumulateGrad add per parameter
+# (14 small launches per step of the benchmark net).  A sink receives ASSIGNMENTS: the trainer guarantees that the
+# parameter is used once per backward pass.  Outside a ``grad_sinks`` block nothing changes.
+_grad_sinks = None
+
+
+class grad_sinks:
+    """``with grad_sinks({param: destination view, ...}, on_delivered=callback):`` - ``on_delivered(param_key)``
+    is called after a backward pass has written a parameter's gradient into its view."""
+
+    def __init__(self, mapping, on_delivered=None):
+        self.map = {p.data_ptr(): (dst, p) for p, dst in mapping.items()}
+        self.on_delivered = on_delivered
+        self.delivered = set()
+
+    def __enter__(self):
+        global _grad_sinks
+        self._outer, _grad_sinks = _grad_sinks, self
+        return self
+
+    def __exit__(self, *exc):
+        global _grad_sinks
+        _grad_sinks = self._outer
+
+
+def grad_destination(param):
+    """The view a parameter's gradient is to be written into (float32, contiguous), or None."""
+    if _grad_sinks is None or param is None:
+        return None
+    hit = _grad_sinks.map.get(param.data_ptr())
+    return hit[0] if hit is not None else None
+
+
+def grad_delivered(param):
+    sinks = _grad_sinks
+    if sinks is None:
+        return
+    hit = sinks.map.get(param.data_ptr())
+    if hit is not None:
+        sinks.delivered.add(param.data_ptr())
+        if sinks.on_delivered is not None:
+            sinks.on_delivered(hit[1])
+
+
 def dtype_code(dtype):
     if dtype == torch.float32:
         return 0
@@ -444,9 +491,9 @@ def bias_relu_(y, bias):
 _bias_ws = {}
 
 
-def relu_bwd_bias(dy, y):
+def relu_bwd_bias(dy, y, dbias_out=None):
     """(dz, dbias): dz = dy masked by y > 0 (written over dy when dy is contiguous and owns its memory),
-    dbias float32 [C] = sum of dz over pixels."""
+    dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given)."""
     C = y.shape[-1]
     assert dy.is_contiguous() and y.is_contiguous()
     key = (C, str(y.device))
@@ -455,7 +502,8 @@ def relu_bwd_bias(dy, y):
         ws = torch.empty([_lib.lib().isg_relu_bwd_bias_workspace_bytes(C) // 4], dtype=torch.float32, device=y.device)
         _bias_ws[key] = ws
     dz = torch.empty_like(dy)
-    dbias = torch.empty([C], dtype=torch.float32, device=y.device)
+    dbias = torch.empty([C], dtype=torch.float32, device=y.device) if dbias_out is None else dbias_out
+    assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == C
     rc = _lib.lib().isg_relu_bwd_bias(_lib.ptr(dy), _lib.ptr(y), y.numel() // C, C, dtype_code(y.dtype), _lib.ptr(dz),
                                       _lib.ptr(dbias), _lib.ptr(ws), _lib.current_stream())
     _lib.check(rc, "isg_relu_bwd_bias")
@@ -505,7 +553,7 @@ def conv_in_fwd(x4, wimg, bias, ks, relu=True):
 _conv_in_ws = {}
 
 
-def conv_in_wgrad(x4, dz, ks):
+def conv_in_wgrad(x4, dz, ks, out=None):
     """float32 [KS,KS,3,cout] weight gradient from the padded image and the masked output gradient."""
     B, H, W, _ = x4.shape
     cout = dz.shape[-1]
@@ -516,7 +564,8 @@ def conv_in_wgrad(x4, dz, ks):
         ws = torch.empty([_lib.lib().isg_conv_in_wgrad_workspace_bytes(int(ks), int(cout)) // 4], dtype=torch.float32,
                          device=x4.device)
         _conv_in_ws[key] = ws
-    dw = torch.empty([ks, ks, 3, cout], dtype=torch.float32, device=x4.device)
+    dw = torch.empty([ks, ks, 3, cout], dtype=torch.float32, device=x4.device) if out is None else out
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == (ks, ks, 3, cout)
     rc = _lib.lib().isg_conv_in_wgrad(_lib.ptr(x4), _lib.ptr(dz), B, H, W, int(ks), int(cout), _lib.ptr(ws), _lib.ptr(dw),
                                       _lib.current_stream())
     _lib.check(rc, "isg_conv_in_wgrad")
@@ -558,7 +607,7 @@ def conv32(x, wimg, bias, ks, relu):
 _conv32_mask_ws = {}
 
 
-def conv32_masked(dz, wimg_dgrad, y_below, ks):
+def conv32_masked(dz, wimg_dgrad, y_below, ks, dbias_out=None):
     """(dz_below, dbias_below): the data gradient of a conv32 / conv16 layer masked by the ReLU of the layer below
     (``y_below`` = that layer's output) and the masked values summed per channel (float32 [C]) - the layer below's
     ReLU backward and bias gradient without a pass of their own (isg_conv32_masked)."""
@@ -571,7 +620,8 @@ def conv32_masked(dz, wimg_dgrad, y_below, ks):
         ws = _conv32_mask_ws[key] = torch.empty([_lib.lib().isg_conv32_masked_workspace_bytes() // 4], dtype=torch.float32,
                                                 device=dz.device)
     out = torch.empty_like(dz)
-    dbias = torch.empty([c], dtype=torch.float32, device=dz.device)
+    dbias = torch.empty([c], dtype=torch.float32, device=dz.device) if dbias_out is None else dbias_out
+    assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == c
     fn = _lib.lib().isg_conv32_masked if c == 32 else _lib.lib().isg_conv16_masked
     rc = fn(_lib.ptr(dz), _lib.ptr(wimg_dgrad), _lib.ptr(y_below), B, H, W, int(ks), _lib.ptr(out), _lib.ptr(dbias),
             _lib.ptr(ws), _lib.current_stream())
@@ -582,7 +632,7 @@ def conv32_masked(dz, wimg_dgrad, y_below, ks):
 _conv32_ws = {}
 
 
-def conv32_wgrad(x, dz, ks):
+def conv32_wgrad(x, dz, ks, out=None):
     B, H, W, c = x.shape
     assert x.is_contiguous() and dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == x.shape and c in (16, 32)
     key = (int(ks), str(x.device))
@@ -591,7 +641,8 @@ def conv32_wgrad(x, dz, ks):
         ws = torch.empty([_lib.lib().isg_conv32_wgrad_workspace_bytes(int(ks)) // 4], dtype=torch.float32,
                          device=x.device)
         _conv32_ws[key] = ws
-    dw = torch.empty([ks, ks, c, c], dtype=torch.float32, device=x.device)
+    dw = torch.empty([ks, ks, c, c], dtype=torch.float32, device=x.device) if out is None else out
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == (ks, ks, c, c)
     fn = _lib.lib().isg_conv32_wgrad if c == 32 else _lib.lib().isg_conv16_wgrad
     rc = fn(_lib.ptr(x), _lib.ptr(dz), B, H, W, int(ks), _lib.ptr(ws), _lib.ptr(dw), _lib.current_stream())
     _lib.check(rc, "isg_conv32_wgrad")

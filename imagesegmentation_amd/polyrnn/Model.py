@@ -122,6 +122,7 @@ class _EncoderChain(torch.autograd.Function):
         for w, b in zip(ws[1:], bs[1:]):
             ys.append(ops.conv32(ys[-1], ops.conv32_pack(w), b.detach().float().contiguous(), w.shape[0], relu=True))
         ctx.save_for_backward(x4, *ys, *ws)
+        ctx.biases = [b.detach() for b in bs]  # (only their addresses are used: where their gradients belong)
         ctx.n = len(ws)
         ctx.dtypes = [p.dtype for p in params]
         return ys[-1]
@@ -130,15 +131,26 @@ class _EncoderChain(torch.autograd.Function):
     def backward(ctx, dy):
         n = ctx.n
         x4, ys, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        bs = ctx.biases
         grads = [None] * (2 * n)
-        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), ys[-1])
+        # a gradient whose parameter has a sink (ops.grad_sinks) is written there by the kernel itself and autograd
+        # gets None for it
+        dst = lambda p: ops.grad_destination(p)
+
+        def hand(slot, param, value, to):
+            if dst(param) is not None:
+                ops.grad_delivered(param)
+            else:
+                grads[slot] = value.to(to)
+        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), ys[-1], dbias_out=dst(bs[n - 1]))
         for k in range(n - 1, 0, -1):
             ks = ws[k].shape[0]
-            grads[2 * k] = ops.conv32_wgrad(ys[k - 1], dz, ks).to(ctx.dtypes[2 * k])
-            grads[2 * k + 1] = dbias.to(ctx.dtypes[2 * k + 1])
-            dz, dbias = ops.conv32_masked(dz, ops.conv32_pack(ws[k], data_gradient=True), ys[k - 1], ks)
-        grads[0] = ops.conv_in_wgrad(x4, dz, ws[0].shape[0]).to(ctx.dtypes[0])
-        grads[1] = dbias.to(ctx.dtypes[1])
+            hand(2 * k, ws[k], ops.conv32_wgrad(ys[k - 1], dz, ks, out=dst(ws[k])), ctx.dtypes[2 * k])
+            hand(2 * k + 1, bs[k], dbias, ctx.dtypes[2 * k + 1])
+            dz, dbias = ops.conv32_masked(dz, ops.conv32_pack(ws[k], data_gradient=True), ys[k - 1], ks,
+                                          dbias_out=dst(bs[k - 1]))
+        hand(0, ws[0], ops.conv_in_wgrad(x4, dz, ws[0].shape[0], out=dst(ws[0])), ctx.dtypes[0])
+        hand(1, bs[0], dbias, ctx.dtypes[1])
         return (None,) + tuple(grads)
 
 
@@ -179,6 +191,44 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
         return torch.relu(z + b.to(dtype).view(1, -1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     y = F.relu(F.conv2d(x, w, b.to(dtype), padding=pad))
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+class _DenseHead(torch.autograd.Function):
+    """logits = flat @ W + b (reference polyrnn/History2LargeExperiment.py:48-50) with float32 master weights and
+    activations in the compute type: the library GEMM runs in the compute type on copies of the weights that are
+    cached until the weights change; the weight gradient (a GEMM in the compute type) lands in the parameter's
+    gradient sink with ONE converting pass when there is one (ops.grad_sinks) - otherwise autograd would convert it
+    to float32 and add it to the gradient in two more passes over its 9.8 M elements."""
+
+    @staticmethod
+    def forward(ctx, flat, w, b, cache):
+        dt = flat.dtype
+        key = (dt, w._version, b._version, w.data_ptr(), ops.weights_epoch())
+        if cache.get("key") != key:
+            cache["key"], cache["w"], cache["b"] = key, w.detach().to(dt), b.detach().to(dt)
+        wc, bc = cache["w"], cache["b"]
+        ctx.save_for_backward(flat, wc)
+        ctx.params = (w.detach(), b.detach())
+        return torch.addmm(bc, flat, wc)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        flat, wc = ctx.saved_tensors
+        w, b = ctx.params
+        dlogits = dlogits.contiguous()
+        d_flat = dlogits @ wc.t() if ctx.needs_input_grad[0] else None
+        dw = flat.t() @ dlogits
+        db = dlogits.sum(dim=0, dtype=torch.float32)
+        out = []
+        for prm, g in ((w, dw), (b, db)):
+            dst = ops.grad_destination(prm)
+            if dst is not None:
+                dst.copy_(g)
+                ops.grad_delivered(prm)
+                out.append(None)
+            else:
+                out.append(g.to(prm.dtype))
+        return d_flat, out[0], out[1], None
 
 
 class _AvgPool(torch.autograd.Function):
@@ -258,6 +308,9 @@ class Model:
         self._early_reduce = parallel.EarlyTailReduce(self._flat_grad, [self.dense_kernel, self.dense_bias], head_at,
                                                       process_group)
         self._events = None
+        self._head_cache = {}
+        # where each parameter's gradient belongs: its view of the flat bucket (ops.grad_sinks)
+        self._sinks = {p: p.grad for p in self.trainable_variables}
         # values of the last evaluation (graph nodes in the reference)
         self.prediction_logits = None
         self.loss = None
@@ -346,16 +399,17 @@ class Model:
             rnn_out = _AvgPool.apply(rnn_out.contiguous(), P // hs)
         flat = rnn_out.reshape(B * T, hs * hs * self.rnn_filters)
         w, b = self.dense_kernel, self.dense_bias
-        if flat.dtype != w.dtype and not torch.is_grad_enabled():
+        if torch.is_grad_enabled() and flat.is_cuda:
+            logits = _DenseHead.apply(flat, w, b, self._head_cache)
+        elif flat.dtype != w.dtype:
             # decode loops call the head once per step with unchanged weights: convert them once
+            cache = self._head_cache
             key = (flat.dtype, w._version, b._version, w.data_ptr(), ops.weights_epoch())
-            if getattr(self, "_head_cast_key", None) != key:
-                self._head_cast = (w.detach().to(flat.dtype), b.detach().to(flat.dtype))
-                self._head_cast_key = key
-            w, b = self._head_cast
+            if cache.get("key") != key:
+                cache["key"], cache["w"], cache["b"] = key, w.detach().to(flat.dtype), b.detach().to(flat.dtype)
+            logits = torch.addmm(cache["b"], flat, cache["w"])
         else:
-            w, b = w.to(flat.dtype), b.to(flat.dtype)
-        logits = torch.addmm(b, flat, w)
+            logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
 
     def forward(self, images, durations, histories, initial_state=None):
@@ -403,13 +457,26 @@ class Model:
                       clip_norm=1.0 if clip else None, norm=norm)
         return norm
 
+    def _on_gradient_delivered(self, param):
+        # a backward pass wrote this parameter's gradient into the flat bucket itself (no AccumulateGrad node ran,
+        # so no post-accumulate hook fired): the early share of the all-reduce counts it here
+        if param is self.dense_kernel or param is self.dense_bias:
+            self._early_reduce._on_grad(param)
+
     def train_step(self, images, durations, histories, targets):
         """Forward, backward, clip, Adam. Returns the (device) loss tensor."""
-        self._flat_grad.zero_()
-        logits, _ = self.forward(images, durations, histories)
-        loss, metrics = self._loss_and_metrics(logits, durations, targets)
-        self._early_reduce.arm()
-        loss.backward()
+        # Every parameter is used once per step, so the hand-written backward passes ASSIGN their gradients into
+        # the flat bucket (ops.grad_sinks) - the dense head's 9.8 M elements included; the zero fill is for what
+        # autograd still accumulates itself (layers on library kernels), i.e. everything but the head's share.
+        self._flat_grad[:self._early_reduce.offset].zero_()
+        with ops.grad_sinks(self._sinks, self._on_gradient_delivered) as sinks:
+            logits, _ = self.forward(images, durations, histories)
+            loss, metrics = self._loss_and_metrics(logits, durations, targets)
+            self._early_reduce.arm()
+            loss.backward()
+        for p in (self.dense_kernel, self.dense_bias):
+            if p.data_ptr() not in sinks.delivered:  # (cannot happen with the head above; kept as a guard)
+                raise RuntimeError("the dense head's gradient was not delivered to the flat bucket")
         self._apply_gradients()
         self.loss = loss.detach()
         self.last_metrics = metrics
