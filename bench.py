@@ -597,18 +597,26 @@ class GpuWorkload:
             idx = rs.randint(0, len(ds), [B])
             images = torch.as_tensor(ds._images[idx], device=self.device).to(self.dtype)
             verts = [ds._vertices[i] for i in idx]
-            for _ in range(2):
-                model.validate_iou(images, verts, summary_prefix=None)
-            torch.cuda.synchronize()
-            reps = 5 if B <= 64 else 2
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                iou = model.validate_iou(images, verts, summary_prefix=None)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / reps * 1e3
+            res = {}
+            for mode, graphs in (("graph", True), ("stepwise", False)):
+                model.decode_graphs = graphs
+                for _ in range(2):
+                    model.validate_iou(images, verts, summary_prefix=None)
+                torch.cuda.synchronize()
+                reps = 5 if B <= 64 else 2
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    iou = model.validate_iou(images, verts, summary_prefix=None)
+                torch.cuda.synchronize()
+                res[mode] = ((time.perf_counter() - t0) / reps * 1e3, iou, getattr(model, "decode_host_launches", None))
+            ms, iou, launches = res["graph"]
+            # ms_per_decode: validate_iou end to end (upload, decode loop as one graph launch, polygon assembly,
+            # rasteriser + IoU, one copy back); *_stepwise: the same with every kernel launched from the host
             out["B%d" % B] = {"ms_per_decode": ms, "ms_per_sequence": ms / B, "sequences_per_s": B / ms * 1e3,
-                              "mean_iou_untrained": iou}
-        out["launches_per_vertex"] = getattr(model, "decode_launches_per_step", None)
+                              "host_launches_of_the_loop": launches, "ms_per_decode_stepwise": res["stepwise"][0],
+                              "host_launches_of_the_loop_stepwise": res["stepwise"][2],
+                              "same_iou_both_ways": bool(res["stepwise"][1] == iou), "mean_iou_untrained": iou}
+        out["kernels_per_vertex"] = getattr(model, "decode_launches_per_step", None)
         return out
 
     # -- legs with collectives (training steps / RL updates inside) --------------------------------------------

@@ -399,11 +399,25 @@ class RecurrentStepper:
         self._seq = SequenceInput(static=static, hist_points=pts)
         self.packed = [self._seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
         self._seq.prepare(dt, self.packed[0].cs)
-        self.H = [torch.zeros([2, B, H, W, F], dtype=dt, device=dev) for _ in cells]
         # (the cell state in the type the sequence node stores it in: a decode loop repeats a training pass's numbers)
-        self.C = [torch.zeros([2, B, H, W, F], dtype=_state_dtype(self.packed[l], B, H, W, cf if l == 0 else None),
-                              device=dev) for l in range(len(cells))]
-        self.out = torch.zeros([B, 1, H, W, F], dtype=dt, device=dev)
+        cdts = [_state_dtype(self.packed[l], B, H, W, cf if l == 0 else None) for l in range(len(cells))]
+        # one zero fill per storage type instead of one per buffer (a decode loop at a small batch is a chain of
+        # launches of a few microseconds each: every launch counts)
+        n, L = B * H * W * F, len(cells)
+        n16 = (2 * L + 1) * n if dt == torch.bfloat16 else 0
+        flat16 = torch.zeros([n16 + 2 * n * sum(1 for c in cdts if c == torch.bfloat16)], dtype=torch.bfloat16, device=dev)
+        flat32 = torch.zeros([(0 if dt == torch.bfloat16 else (2 * L + 1) * n) +
+                              2 * n * sum(1 for c in cdts if c == torch.float32)], dtype=torch.float32, device=dev)
+        used = {torch.bfloat16: 0, torch.float32: 0}
+        pools = {torch.bfloat16: flat16, torch.float32: flat32}
+
+        def take(count, dtype, shape):
+            o = used[dtype]
+            used[dtype] = o + count
+            return pools[dtype][o:o + count].view(shape)
+        self.H = [take(2 * n, dt, [2, B, H, W, F]) for _ in cells]
+        self.C = [take(2 * n, cdts[l], [2, B, H, W, F]) for l in range(L)]
+        self.out = take(n, dt, [B, 1, H, W, F])
         self.cur = 0
         self._stride = H * W * F
         if initial_state is not None:

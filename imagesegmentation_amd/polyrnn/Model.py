@@ -246,6 +246,55 @@ class _AvgPool(torch.autograd.Function):
         return d.repeat_interleave(k, dim=-3).repeat_interleave(k, dim=-2), None
 
 
+class _DecodeGraph:
+    """The decode loop of one (model, batch size) captured as a HIP graph: inputs are copied into the graph's own
+    buffers, one launch replays encoder + weight packing + T x (cells, head, decode step) + the assembly and
+    rasterisation of the predicted polygons, and the results are read from its buffers.  The packing kernels are
+    part of the graph and read the master weights where they live (the flat parameter buffer), so a replay after an
+    optimiser step decodes with the new weights.  The graph's buffers are overwritten by the next replay: what is
+    handed out of ``run`` are copies, except the recurrent state (a view that lives until then)."""
+
+    def __init__(self, model, images_dev, vt, nvt):
+        self.images = images_dev.clone()
+        self.vt, self.nvt = vt.clone(), nvt.clone()
+
+        def body():
+            predicted, durations, pts0, stepper = model._decode_body(self.images, self.vt, self.nvt)
+            return predicted, durations, pts0, stepper, model._iou_body(predicted, durations, pts0, self.vt, self.nvt)
+        # one eager pass first: library handles and workspaces come into being outside the capture
+        body()
+        torch.cuda.synchronize()
+        # everything cached from the weights is rebuilt inside the capture, so that the rebuild is part of the graph
+        self._drop_weight_caches(model)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+            self.predicted, self.durations, self.pts0, self.stepper, self.back = body()
+        # (what the capture cached belongs to the graph's memory pool and holds nothing until a replay)
+        self._drop_weight_caches(model)
+
+    @staticmethod
+    def _drop_weight_caches(model):
+        for cell in model.rnn.cells:
+            cell._packed = None
+        model._head_cache.clear()
+
+    @staticmethod
+    def _load(dst, src):
+        """Host array or tensor -> the graph's buffer, converting on the way, without blocking the host."""
+        if not torch.is_tensor(src):
+            src = torch.from_numpy(np.ascontiguousarray(src))
+            if src.numel() * src.element_size() <= (1 << 22):
+                src = src.pin_memory()
+        dst.copy_(src, non_blocking=True)
+
+    def run(self, images, vt, nvt):
+        self._load(self.images, images)
+        self._load(self.vt, vt)
+        self._load(self.nvt, nvt)
+        self.graph.replay()
+        return self
+
+
 class Model:
     #: overridden per experiment (reference: each *Experiment.py's ExperimentModel._build_graph)
     encoder_spec = ((16, 5), (16, 5), (16, 3))
@@ -309,6 +358,7 @@ class Model:
                                                       process_group)
         self._events = None
         self._head_cache = {}
+        self._decode_graph_cache = {}
         # where each parameter's gradient belongs: its view of the flat bucket (ops.grad_sinks)
         self._sinks = {p: p.grad for p in self.trainable_variables}
         # values of the last evaluation (graph nodes in the reference)
@@ -560,19 +610,20 @@ class Model:
     #: History0Experiment builds the predicted polygon from the predictions alone (its :158)
     iou_prepend_history = True
 
-    def _decode_on_device(self, images, true_vertices):
-        """The reference's per-vertex loop (polyrnn/Model.py:218-249) with everything between two recurrence
-        steps on the device: one fused cell launch per layer, the head GEMM and ONE isg_decode_step launch
-        (argmax, stop rule / end-token rule, predicted polygon, history roll) per vertex - no host round trip
-        inside the loop.  Returns int32 device tensors (predicted [B,T,2], durations [B], first history
-        points [B,hist,2], true polygons [B,vmax,2], their vertex counts [B])."""
-        B = len(true_vertices)
+    #: Decode loops of one batch size are captured once as a HIP graph and replayed (``_DecodeGraph``); False (or
+    #: ISG_NO_DECODE_GRAPH=1) launches every kernel of every vertex from the host instead.
+    decode_graphs = True
+
+    def _decode_body(self, images_dev, vt, nvt):
+        """Everything between the uploaded inputs and the decoded polygons, launches only (no host round trip):
+        encoder, first history points and closing vertices from the true polygons, then per vertex one fused cell
+        launch per layer, the head GEMM and ONE isg_decode_step launch (argmax, stop rule / end-token rule,
+        predicted polygon, history roll) - the reference's loop, polyrnn/Model.py:218-249.  Returns (predicted
+        [B,T,2], durations [B], first history points [B,hist,2], stepper)."""
+        B = vt.shape[0]
         T, hist, dev = self.max_timesteps, self.history_length, self.device
-        vt_host, nvt_host = util.pack_polygons([np.asarray(v) for v in true_vertices])
-        vt = ops.upload(vt_host, dev, torch.int32)
-        nvt = ops.upload(nvt_host, dev, torch.int32)
         with torch.no_grad():
-            features = self.encode(images)
+            features = self.encode(images_dev)
             n = nvt.long()[:, None]
             # frame i of the first step shows true_vertices[len - hist + i] (create_history with
             # end_idx = len(v) - 1, Model.py:224-226); the closing vertex is true_vertices[-hist] (Model.py:240)
@@ -589,25 +640,68 @@ class Model:
                 out = stepper.step(pts, durations=required, t=0)
                 decode.decode_step(self.head(out)[:, 0], self.head_size, self.end_token, close, required, durations,
                                    predicted, i, pts)
-        self.rnn_final_state = stepper.state
+        return predicted, durations, pts0, stepper
+
+    def _decode_graph_for(self, B, image_shape, vmax):
+        """The captured loop for this batch size, or None when graphs are off / the shape has none."""
+        if not self.decode_graphs or os.environ.get("ISG_NO_DECODE_GRAPH") or vmax != util.VMAX_DEFAULT:
+            return None
+        key = (B, tuple(image_shape))
+        graph = self._decode_graph_cache.get(key)
+        if graph is None:
+            if len(self._decode_graph_cache) >= 4:  # (each holds its buffers: keep a handful of batch sizes)
+                self._decode_graph_cache.pop(next(iter(self._decode_graph_cache)))
+            dev = self.device
+            images = torch.zeros(image_shape, dtype=self.compute_dtype, device=dev)
+            vt = torch.zeros([B, vmax, 2], dtype=torch.int32, device=dev)
+            vt[:, 1, 0], vt[:, 2, 1] = 1, 1  # (a valid triangle per sample for the capture's own eager pass)
+            nvt = torch.full([B], 3, dtype=torch.int32, device=dev)
+            try:
+                graph = _DecodeGraph(self, images, vt, nvt)
+            except RuntimeError as err:  # a library op inside the loop that cannot be captured
+                import warnings
+                warnings.warn("decode loop not captured as a graph (%s): launching it step by step" % err)
+                self.decode_graphs = False
+                return None
+            self._decode_graph_cache[key] = graph
+        return graph
+
+    def _decode_run(self, images, true_vertices):
+        """Decode + IoU counts on the device.  Returns (predicted, durations, pts0, vt, nvt, back) - ``back`` int32
+        [B, 2 T + 3] = predicted vertices, durations, intersection, union per sample."""
+        B = len(true_vertices)
+        dev = self.device
+        vt_host, nvt_host = util.pack_polygons([np.asarray(v) for v in true_vertices])
         #: device launches per decoded vertex: the cells, the head GEMM, the decode step
         self.decode_launches_per_step = len(self.rnn.cells) + 2
-        return predicted, durations, pts0, vt, nvt
+        shape = tuple(images.shape)
+        graph = self._decode_graph_for(B, shape, vt_host.shape[1])
+        if graph is not None:
+            g = graph.run(images, vt_host, nvt_host)
+            #: host launches of the last decode loop (graph replay: the whole loop is one)
+            self.decode_host_launches = 1
+            self.rnn_final_state = g.stepper.state
+            return g.predicted, g.durations, g.pts0, g.vt, g.nvt, g.back
+        vt = ops.upload(vt_host, dev, torch.int32)
+        nvt = ops.upload(nvt_host, dev, torch.int32)
+        images_dev = self._to_dev(images, self.compute_dtype).contiguous()
+        predicted, durations, pts0, stepper = self._decode_body(images_dev, vt, nvt)
+        self.decode_host_launches = self.max_timesteps * self.decode_launches_per_step
+        self.rnn_final_state = stepper.state
+        return predicted, durations, pts0, vt, nvt, self._iou_body(predicted, durations, pts0, vt, nvt)
 
-    def decode(self, images, true_vertices):
-        """Autoregressive decode: one recurrence step per vertex with the previous state fed back, argmax
-        vertex, history shifted by np.roll(+1).  Returns (predicted_vertices [B,T,2] float64,
-        prediction_durations [B]) on the host - one device-to-host copy, after the loop."""
-        predicted, durations, _, _, _ = self._decode_on_device(images, true_vertices)
-        B = predicted.shape[0]
-        both = torch.cat([predicted.reshape(B, -1), durations[:, None]], dim=1).cpu().numpy()
-        return both[:, :-1].reshape(B, -1, 2).astype(np.float64), both[:, -1].astype(np.uint32)
+    def _decode_on_device(self, images, true_vertices):
+        """The reference's per-vertex loop (polyrnn/Model.py:218-249) on the device.  The whole loop - T x (L cell
+        launches + head GEMM + decode step), the encoder and the weight packing in front of it - is ONE graph
+        launch after the first decode of a batch size (``_DecodeGraph``); without graphs it is L + 2 launches per
+        vertex.  No host round trip inside either way.  Returns int32 device tensors (predicted [B,T,2],
+        durations [B], first history points [B,hist,2], true polygons [B,vmax,2], their vertex counts [B]); with
+        graphs they are the graph's buffers, valid until the next decode of that batch size."""
+        return self._decode_run(images, true_vertices)[:5]
 
-    def validate_iou(self, images, true_vertices, summary_prefix='valid', additional_feed_args={}):
-        """Decode, then mask IoU of every predicted polygon against its true one (reference Model.py:208-260):
-        polygons are assembled and rasterised on the device; predictions, durations and the IoU counts come
-        back in one copy."""
-        predicted, durations, pts0, vt, nvt = self._decode_on_device(images, true_vertices)
+    def _iou_body(self, predicted, durations, pts0, vt, nvt):
+        """Predicted polygons assembled and rasterised against the true ones on the device (reference
+        polyrnn/Model.py:252-260): int32 [B, 2 T + 3] = predicted vertices, durations, intersection, union."""
         B, T = predicted.shape[0], self.max_timesteps
         P, hist = self.prediction_size, self.history_length
         count = durations if self.iou_slice_by_duration else torch.full_like(durations, T)
@@ -618,8 +712,22 @@ class Model:
         vmax = max(vp.shape[1], vt.shape[1], util.VMAX_DEFAULT)
         pad = lambda v: torch.nn.functional.pad(v, (0, 0, 0, vmax - v.shape[1])).contiguous()
         inter, union = util.raster_iou(pad(vp), count.contiguous(), pad(vt), nvt, P)
-        back = torch.cat([predicted.reshape(B, -1), durations[:, None], inter[:, None], union[:, None]], dim=1)
-        back = back.cpu().numpy()
+        return torch.cat([predicted.reshape(B, -1), durations[:, None], inter[:, None], union[:, None]], dim=1)
+
+    def decode(self, images, true_vertices):
+        """Autoregressive decode: one recurrence step per vertex with the previous state fed back, argmax
+        vertex, history shifted by np.roll(+1).  Returns (predicted_vertices [B,T,2] float64,
+        prediction_durations [B]) on the host - one device-to-host copy, after the loop."""
+        back = self._decode_run(images, true_vertices)[5].cpu().numpy()
+        B = back.shape[0]
+        return back[:, :-3].reshape(B, -1, 2).astype(np.float64), back[:, -3].astype(np.uint32)
+
+    def validate_iou(self, images, true_vertices, summary_prefix='valid', additional_feed_args={}):
+        """Decode, then mask IoU of every predicted polygon against its true one (reference Model.py:208-260):
+        polygons are assembled and rasterised on the device; predictions, durations and the IoU counts come
+        back in one copy."""
+        back = self._decode_run(images, true_vertices)[5].cpu().numpy()
+        B, T = back.shape[0], self.max_timesteps
         ious = back[:, -2].astype(np.float64) / back[:, -1].astype(np.float64)
         self.last_ious = ious
         self.last_predicted_vertices = back[:, :-3].reshape(B, T, 2).astype(np.float64)
