@@ -503,6 +503,9 @@ class GpuWorkload:
                                  head_size=head_size)
         bt = make_batch(size, batch, model.max_timesteps, model.history_length, head_size, seed=seed,
                         device=self.device, dtype=dtype, end_token=model.end_token)
+        # small grids: a step is hundreds of launches of a few microseconds, the host is the bottleneck - replay the
+        # step as a HIP graph (ISG_NO_STEP_GRAPH=1: launch kernel by kernel, for A/B runs)
+        model.step_graphs = size <= 64 and not os.environ.get("ISG_NO_STEP_GRAPH")
         return model, bt
 
     def close(self):
@@ -522,7 +525,8 @@ class GpuWorkload:
                             (CONFIGS[self.args.config][0], self.size, self.size, self.share["batch"], self.T,
                              len(m.rnn.cells), self.head_size, self.head_size,
                              " (8x-pooled)" if self.head_size != self.size else ""),
-                "mean_duration": float(np.mean(self.batch["durations"]))}
+                "mean_duration": float(np.mean(self.batch["durations"])),
+                "step_as_graph": bool(self.model.step_graphs)}
 
     def allreduce_bytes(self):
         return int(self.model._flat_grad.numel() * 4)
@@ -907,7 +911,8 @@ def run_legs(args, world, rank, w):
             label, bsz = other.pop("label"), other.pop("batch_size")
             sec = time_steps(lambda: w.train_step(**other), 10, 3)
             extra["endtokendeep2"] = {"value": bsz * world / sec, "unit": "sequences/s", "ms_per_step": sec * 1e3,
-                                      "dtype": args.dtype, "workload": label, "global_batch": bsz * world}
+                                      "dtype": args.dtype, "workload": label, "global_batch": bsz * world,
+                                      "step_as_graph": bool(getattr(other.get("model"), "step_graphs", False))}
             del other
             w.release()
         if rank == 0:

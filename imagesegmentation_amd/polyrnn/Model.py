@@ -295,6 +295,37 @@ class _DecodeGraph:
         return self
 
 
+class _StepGraph:
+    """Forward pass, loss, metrics and backward pass of one training step for one input shape and one number of
+    recurrence steps, captured as a HIP graph.  On small grids (the reference's 28 x 28) a step is a few hundred
+    launches of a few microseconds each and the host cannot issue them as fast as the GPU retires them; replayed
+    as a graph they cost one launch.  Inputs are copied into the graph's buffers; the gradients land in the
+    model's flat bucket (the backward passes write there, ops.grad_sinks); the exchange between ranks, the clip
+    and Adam follow outside the graph.  Weight packing and the head's weight copies are part of the graph and read
+    the master weights where they live, so every replay uses the current weights."""
+
+    def __init__(self, model, images, durations, points, targets, steps):
+        dev = model.device
+        self.images = torch.zeros(images.shape, dtype=model.compute_dtype, device=dev)
+        self.durations = torch.zeros(durations.shape, dtype=torch.int32, device=dev)
+        self.points = torch.zeros(points.shape, dtype=torch.int32, device=dev)
+        self.targets = torch.zeros(targets.shape, dtype=torch.int32, device=dev)
+        self.steps = steps
+        self.load(images, durations, points, targets)
+        model._step_body(self.images, self.durations, self.points, self.targets, steps)  # eager: workspaces, handles
+        torch.cuda.synchronize()
+        _DecodeGraph._drop_weight_caches(model)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+            self.loss, self.metrics = model._step_body(self.images, self.durations, self.points, self.targets, steps)
+        _DecodeGraph._drop_weight_caches(model)
+
+    def load(self, images, durations, points, targets):
+        for dst, src in ((self.images, images), (self.durations, durations), (self.points, points),
+                         (self.targets, targets)):
+            _DecodeGraph._load(dst, src)
+
+
 class Model:
     #: overridden per experiment (reference: each *Experiment.py's ExperimentModel._build_graph)
     encoder_spec = ((16, 5), (16, 5), (16, 3))
@@ -359,6 +390,7 @@ class Model:
         self._events = None
         self._head_cache = {}
         self._decode_graph_cache = {}
+        self._step_graph_cache = {}
         # where each parameter's gradient belongs: its view of the flat bucket (ops.grad_sinks)
         self._sinks = {p: p.grad for p in self.trainable_variables}
         # values of the last evaluation (graph nodes in the reference)
@@ -462,12 +494,13 @@ class Model:
             logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
 
-    def forward(self, images, durations, histories, initial_state=None):
+    def forward(self, images, durations, histories, initial_state=None, steps=None):
         features = self.encode(images)
         seq = self._sequence_input(features, histories)
         # durations already on the device (a batch from data.DeviceBatchBuilder) are not fetched back: all
-        # max_timesteps steps run under the per-sample mask
-        steps = self.max_timesteps if torch.is_tensor(durations) and durations.is_cuda else None
+        # max_timesteps steps (or ``steps``, a bound the caller knows) run under the per-sample mask
+        if steps is None:
+            steps = self.max_timesteps if torch.is_tensor(durations) and durations.is_cuda else None
         # the head's average pool rides inside the recurrence node: its gradient is never materialised
         rnn_out, final = dynamic_rnn(self.rnn, seq, sequence_length=durations, initial_state=initial_state,
                                      time_major=False, output_pool=self.prediction_size // self.head_size, steps=steps)
@@ -513,22 +546,76 @@ class Model:
         if param is self.dense_kernel or param is self.dense_bias:
             self._early_reduce._on_grad(param)
 
-    def train_step(self, images, durations, histories, targets):
-        """Forward, backward, clip, Adam. Returns the (device) loss tensor."""
+    #: True: training steps whose history arrives as vertex points are captured as HIP graphs, one per input shape
+    #: and number of recurrence steps (``_StepGraph``), and replayed.  For launch-bound sizes (28 x 28 grids); at
+    #: 224 x 224 the step is bound by its kernels and eager launches lose nothing.  Off by default: the eager step
+    #: overlaps the head's share of the gradient exchange with the backward pass, the graph step exchanges after it.
+    step_graphs = False
+
+    def _step_body(self, images, durations, histories, targets, steps=None, arm=False):
+        """Zero fill, forward, loss, metrics, backward: everything of a step up to the gradient exchange."""
         # Every parameter is used once per step, so the hand-written backward passes ASSIGN their gradients into
         # the flat bucket (ops.grad_sinks) - the dense head's 9.8 M elements included; the zero fill is for what
         # autograd still accumulates itself (layers on library kernels), i.e. everything but the head's share.
         self._flat_grad[:self._early_reduce.offset].zero_()
         with ops.grad_sinks(self._sinks, self._on_gradient_delivered) as sinks:
-            logits, _ = self.forward(images, durations, histories)
+            logits, _ = self.forward(images, durations, histories, steps=steps)
             loss, metrics = self._loss_and_metrics(logits, durations, targets)
-            self._early_reduce.arm()
+            if arm:
+                self._early_reduce.arm()
             loss.backward()
         for p in (self.dense_kernel, self.dense_bias):
             if p.data_ptr() not in sinks.delivered:  # (cannot happen with the head above; kept as a guard)
                 raise RuntimeError("the dense head's gradient was not delivered to the flat bucket")
+        return loss.detach(), metrics
+
+    def _encoder_is_native(self):
+        """Whether every encoder layer runs on this library's kernels (bf16; first layer 3 -> 16 / 32 channels, the
+        others 16 -> 16 / 32 -> 32): no vendor convolution anywhere in the step."""
+        (w0, _), rest = self.encoder[0], self.encoder[1:]
+        return self.compute_dtype == torch.bfloat16 and len(self.encoder) >= 2 and \
+            ops.conv_in_supported(w0, self.compute_dtype, self.device) and \
+            all(ops.conv32_supported(w, self.compute_dtype, self.device) and w.shape[2] == w0.shape[3] for w, _ in rest)
+
+    def _graphed_step(self, images, durations, points, targets):
+        """The step body as a graph replay, or None when this call has no graph form."""
+        if not (torch.is_tensor(points) or isinstance(points, np.ndarray)):
+            return None
+        if not self._encoder_is_native():
+            return None  # (the vendor convolution's backward does not survive a stream capture)
+        pts_int = (not points.is_floating_point()) if torch.is_tensor(points) else points.dtype.kind in "iu"
+        if not pts_int or len(points.shape) != 4:
+            return None  # dense history frames: the eager path
+        if torch.is_tensor(durations):
+            steps = self.max_timesteps  # lengths that live on the device stay there: every step runs masked
+        else:
+            d = np.asarray(durations)
+            steps = int(min(max(int(d.max()) if d.size else 0, 0), self.max_timesteps))
+        key = (tuple(images.shape), tuple(points.shape), tuple(np.shape(targets)), steps)
+        graph = self._step_graph_cache.get(key)
+        if graph is None:
+            if len(self._step_graph_cache) >= 2 * self.max_timesteps + 2:
+                self._step_graph_cache.pop(next(iter(self._step_graph_cache)))
+            try:
+                graph = _StepGraph(self, images, durations, points, targets, steps)
+            except RuntimeError as err:
+                import warnings
+                warnings.warn("training step not captured as a graph (%s): launching it kernel by kernel" % err)
+                self.step_graphs = False
+                return None
+            self._step_graph_cache[key] = graph
+        graph.load(images, durations, points, targets)
+        graph.graph.replay()
+        return graph.loss, graph.metrics
+
+    def train_step(self, images, durations, histories, targets):
+        """Forward, backward, clip, Adam. Returns the (device) loss tensor."""
+        done = self._graphed_step(images, durations, histories, targets) if self.step_graphs else None
+        if done is None:
+            done = self._step_body(images, durations, histories, targets, arm=True)
+        loss, metrics = done
         self._apply_gradients()
-        self.loss = loss.detach()
+        self.loss = loss
         self.last_metrics = metrics
         return self.loss
 
