@@ -37,7 +37,8 @@ def main():
         pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
         x = torch.randn([B, P, P, cs], device=dev).to(dt)
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
-        c0, c1 = torch.randn([B, P, P, F], device=dev), torch.randn([B, P, P, F], device=dev)
+        c0, c1 = torch.randn([B, P, P, F], device=dev).to(dt), torch.randn([B, P, P, F], device=dev)
+        c0f = c0.float()
         gates = torch.rand([B, P, P, F, 4], device=dev).to(dt)
         factors = torch.rand([B, P, P, F // 2, 4, 2], device=dev).to(dt)
         dh_above = torch.randn([B, P, P, F], device=dev).to(dt)
@@ -53,7 +54,7 @@ def main():
                                       hist_points=pts)
 
         def three():
-            ops.pointwise_bwd(gates, c0, c1, dh_above, P * P * F, dh, dc, dy=dy, dc_prev=dc2)
+            ops.pointwise_bwd(gates, c0f, c1, dh_above, P * P * F, dh, dc, dy=dy, dc_prev=dc2)
             ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, True, hist_points=pts, hist=hist, mode=ops.WGRAD_DEFER, workspace=ws)
             ops.dgrad(dy, packed, dh2, dx=dx, dx_channels=dx.shape[-1], dx_accumulate=acc)
 
