@@ -185,6 +185,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             const unsigned pixel = (unsigned)((row0 + cy) * p.W + cx);
             const unsigned chunk_bytes = (inf >> 22) & 0x70u;
             // byte offsets fit 32 bits (checked on the host): a scalar base plus one vector offset per load
+#ifdef ISG_DIAG_NOLOAD  // diagnostic build: the launch without its tile loads
+            if (true) { st[j] = make_uint4(pixel, chunk_bytes, 0u, 0u); continue; }
+#endif
             if (j < K::NL0)
                 st[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.in0) +
                                                         (size_t)(pixel * (unsigned)(C0 * 2) + chunk_bytes));
@@ -251,8 +254,12 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
             // the forward image interleaves the row tiles per k-step; the data-gradient image keeps each row
             // tile's k-steps together (a launch may also take a single tile of it)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t) {
+#ifdef ISG_DIAG_FEWER_LDS  // diagnostic build (wrong results): the k-loop with half of its LDS reads
+                if (s >= NBUF) { asm volatile("" : "+v"(a[slot][t])); continue; }
+#endif
                 a[slot][t] = *reinterpret_cast<const bf16x8*>(aw + (MODE == 1 ? t * K::NS + s : s * MT + t) * 1024);
+            }
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
             {
@@ -373,7 +380,11 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                     for (int k = 0; k < 8; ++k) cp[k] = __uint_as_float(w[k]);
                 }
                 constexpr bool factors = SF;
+#ifdef ISG_DIAG_NOFSTORE  // diagnostic build: the launch without the stores of what backward keeps
+                T* gd = nullptr;
+#else
                 T* gd = p.gates ? static_cast<T*>(p.gates) + pixel * NG + 32 * half : nullptr;
+#endif
                 float hn[8], cn[8], gprev[4];
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
@@ -413,6 +424,9 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                             gprev[0] = s0, gprev[1] = s1, gprev[2] = fg, gprev[3] = og;
                         }
                     }
+#ifdef ISG_DIAG_NOHC  // diagnostic build: the launch without its state stores (one lane in 2^20 keeps the values live)
+                if (__builtin_expect(hn[0] + cn[1] != 123.456f, 1)) continue;
+#endif
                 if constexpr (CB) {
                     store8(reinterpret_cast<T*>(p.c_out) + so, cn);
                 } else {

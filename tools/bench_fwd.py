@@ -26,7 +26,7 @@ def main():
         pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
         x = torch.randn([B, P, P, cs], device=dev).to(dt)
         h = (torch.randn([B, P, P, F], device=dev) * 0.5).to(dt)
-        c = torch.randn([B, P, P, F], device=dev)
+        c = torch.randn([B, P, P, F], device=dev).to(dt)  # the cell state as the bf16 training step stores it
         h2, c2 = torch.empty_like(h), torch.empty_like(c)
         saved = torch.empty([B, P, P, F, 4], dtype=dt, device=dev)
         for name, layout in (("gates", ops.SAVE_GATES), ("factors", ops.SAVE_FACTORS)):

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "tools", "_build", "libisg_stamps.so")
+OUT = os.environ.get("ISG_STAMP_LIBRARY") or os.path.join(ROOT, "tools", "_build", "libisg_stamps.so")
 
 
 def build():
@@ -49,7 +49,7 @@ def main():
         cs = packed.cs
         x = torch.randn([B, P, P, cs], device=dev).bfloat16()
         h = torch.randn([B, P, P, F], device=dev).bfloat16()
-        c = torch.randn([B, P, P, F], device=dev)
+        c = torch.randn([B, P, P, F], device=dev).bfloat16()
         pts = torch.randint(0, P, [B, hist, 2], device=dev, dtype=torch.int32) if hist else None
         gates = torch.empty([B, P, P, F, 4], dtype=torch.bfloat16, device=dev)
         dy = torch.randn([B, P, P, F, 4], device=dev).bfloat16()
@@ -60,7 +60,8 @@ def main():
         db = torch.zeros_like(cell.bias)
         # wgrad rows: "group" 0 = wave 0, 1 = wave 7; phases: load issue, k-loop, wait + LDS writes, -, barrier
         for label, fn in (("cell_fwd C=%d" % C, lambda: ops.cell_fwd(x, h, c, packed, gates=gates if keep_gates else None,
-                                                                     save_gates=keep_gates, hist_points=pts)),
+                                                                     save_gates=keep_gates, hist_points=pts,
+                                                                     save_layout=ops.SAVE_FACTORS)),
                           ("dgrad C=%d" % C, lambda: ops.dgrad(dy, packed, dhp, dx=dx, dx_channels=cs)),
                           ("wgrad C=%d" % C, lambda: ops.wgrad(x, h, dy, packed.c, dwx, dwh, db, False,
                                                                hist_points=pts, hist=hist))):
