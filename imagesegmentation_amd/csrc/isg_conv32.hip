@@ -229,15 +229,21 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                         recv[c][w] = __shfl_xor(send, 32);
                     }
                 const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
+                unsigned out[K::SPT][4];
+#pragma unroll
+                for (int c = 0; c < K::SPT; ++c) {
+                    // (the row group this lane keeps, 2 c + half, by selects: a register array indexed with a
+                    // per-lane value would live in scratch memory)
+                    const unsigned k0 = half ? pk[2 * c + 1][0] : pk[2 * c][0], k1 = half ? pk[2 * c + 1][1] : pk[2 * c][1];
+                    out[c][0] = half ? recv[c][0] : k0, out[c][1] = half ? recv[c][1] : k1;
+                    out[c][2] = half ? k0 : recv[c][0], out[c][3] = half ? k1 : recv[c][1];
+                }
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 if (gy < p.H && gx < p.W) {
                     char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2);
 #pragma unroll
-                    for (int c = 0; c < K::SPT; ++c) {
-                        const int g = 2 * c + half;
-                        const uint4 out = half ? make_uint4(recv[c][0], recv[c][1], pk[g][0], pk[g][1])
-                                               : make_uint4(pk[g][0], pk[g][1], recv[c][0], recv[c][1]);
-                        *reinterpret_cast<uint4*>(dst + g * 16) = out;
-                    }
+                    for (int c = 0; c < K::SPT; ++c)
+                        *reinterpret_cast<u32x4*>(dst + (2 * c + half) * 16) = u32x4{out[c][0], out[c][1], out[c][2], out[c][3]};
                 }
             }
         }
