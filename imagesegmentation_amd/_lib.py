@@ -28,11 +28,14 @@ SIGNATURES = {
                             _vp]),
     "isg_softmax_xent_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_softmax_xent_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp]),
+    "isg_sequence_xent_fwd": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "isg_softmax_xent_mean_bwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "isg_argmax_rows": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_sample_rows": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp]),
     "isg_sample_actions": (_int, [_vp, _int, _int, _int, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int, _vp, _vp]),
     "isg_decode_step": (_int, [_vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _int, _vp]),
     "isg_sequence_metrics": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "isg_sequence_summary": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),
     "isg_relu_bwd_bias": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp, _vp]),
@@ -62,6 +65,7 @@ SIGNATURES = {
     "isg_convlstm_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                      _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _int, _vp]),
     "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),
+    "isg_refresh_derived": (_int, [_vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_pooled_fwd_supported": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
     "isg_convlstm_cell_fwd_pooled": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                             _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _int, _vp, _ll, _vp]),

@@ -102,12 +102,21 @@ class ConvLSTMCell(torch.nn.Module):
         """Operand images of the current weights; rebuilt whenever a parameter changed in place.
         ``hist`` trailing input channels are one-hot history frames handled as a tap scatter."""
         params = (self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias)
+        reg = ops.active_derived()
+        if reg is not None:  # a trainer that refreshes every derived tensor in one launch per step
+            rkey = ("lstm",) + tuple(p.data_ptr() for p in params) + (self.compute_dtype, hist)
+            packed = reg.get(rkey)
+            if packed is not None:
+                return packed
         key = tuple((p.data_ptr(), p._version) for p in params) + (self.compute_dtype, hist, ops.weights_epoch())
         if self._packed is None or self._packed_key != key:
             cs = ops.padded_channels(self.input_to_state_kernel.shape[2] - hist, self.compute_dtype)
             self._packed = ops.PackedWeights(self.input_to_state_kernel, self.hidden_to_state_kernel, self.bias, cs,
                                              self.compute_dtype, hist=hist)
             self._packed_key = key
+            if reg is not None and reg.owns(*params):
+                pw = self._packed
+                reg.record(rkey, pw, ["fwd", "dgrad", "hist_table"], pw.repack, params)
         return self._packed
 
     def forward(self, x, h, scope=None):

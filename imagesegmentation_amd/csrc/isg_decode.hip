@@ -45,7 +45,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void xent_fwd_kernel(const T* 
                                                                       const float* __restrict__ weights, int rows,
                                                                       int cols, float* __restrict__ loss_rows,
                                                                       float* __restrict__ lse_rows,
-                                                                      int* __restrict__ argmax_rows) {
+                                                                      int* __restrict__ argmax_rows,
+                                                                      const int* __restrict__ targets_xy, int grid_side,
+                                                                      int* __restrict__ labels_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -77,7 +79,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void xent_fwd_kernel(const T* 
         if (lse_rows) lse_rows[row] = lse;
         if (argmax_rows) argmax_rows[row] = bi;
         if (loss_rows) {
-            const int y = labels[row];
+            // (targets given as grid positions: class = x * side + y, reference polyrnn/Model.py:39)
+            const int y = targets_xy ? targets_xy[2 * row] * grid_side + targets_xy[2 * row + 1] : labels[row];
+            if (labels_out) labels_out[row] = y;
             float l = (y >= 0 && y < cols) ? lse - ld(z, y) : NAN;  // TF yields NaN for a bad label
             if (weights) l *= weights[row];
             loss_rows[row] = l;
@@ -92,14 +96,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void xent_bwd_kernel(const T* 
                                                                       const float* __restrict__ lse_rows,
                                                                       const float* __restrict__ row_scale,
                                                                       float uniform_scale, int rows, int cols,
-                                                                      T* __restrict__ dlogits) {
+                                                                      T* __restrict__ dlogits,
+                                                                      const float* __restrict__ upstream) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* z = logits + (size_t)row * cols;
     T* d = dlogits + (size_t)row * cols;
     const float lse = lse_rows[row];
-    const float sc = (row_scale ? row_scale[row] : 1.0f) * uniform_scale;
+    const float sc = (row_scale ? row_scale[row] : 1.0f) * uniform_scale * (upstream ? *upstream : 1.0f);
     const int y = labels[row];
     for (int c = lane; c < cols; c += 64) {
         const float p = expf(ld(z, c) - lse);
@@ -214,10 +219,13 @@ int check_rows(const char* who, int rows, int cols, int dtype) {
 __global__ __launch_bounds__(256) void sequence_metrics_kernel(const int* __restrict__ pred,
                                                               const int* __restrict__ targets,
                                                               const int* __restrict__ durations, int B, int T, int P,
-                                                              double* __restrict__ out) {
-    __shared__ double red[3][256];
-    double correct = 0.0, esum = 0.0, emax = 0.0;
+                                                              double* __restrict__ out,
+                                                              const float* __restrict__ loss_rows,
+                                                              float* __restrict__ loss_mean) {
+    __shared__ double red[4][256];
+    double correct = 0.0, esum = 0.0, emax = 0.0, lsum = 0.0;
     for (int r = threadIdx.x; r < B * T; r += 256) {
+        if (loss_rows) lsum += (double)loss_rows[r];
         const int b = r / T, t = r - b * T;
         const bool live = t < durations[b];
         const int tx = targets[2 * r], ty = targets[2 * r + 1];
@@ -229,13 +237,14 @@ __global__ __launch_bounds__(256) void sequence_metrics_kernel(const int* __rest
         esum += e;
         emax = fmax(emax, e);
     }
-    red[0][threadIdx.x] = correct, red[1][threadIdx.x] = esum, red[2][threadIdx.x] = emax;
+    red[0][threadIdx.x] = correct, red[1][threadIdx.x] = esum, red[2][threadIdx.x] = emax, red[3][threadIdx.x] = lsum;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             red[0][threadIdx.x] += red[0][threadIdx.x + o];
             red[1][threadIdx.x] += red[1][threadIdx.x + o];
             red[2][threadIdx.x] = fmax(red[2][threadIdx.x], red[2][threadIdx.x + o]);
+            red[3][threadIdx.x] += red[3][threadIdx.x + o];
         }
         __syncthreads();
     }
@@ -243,6 +252,10 @@ __global__ __launch_bounds__(256) void sequence_metrics_kernel(const int* __rest
         long long num = 0;
         for (int b = 0; b < B; ++b) num += durations[b];
         out[0] = red[0][0], out[1] = red[1][0], out[2] = red[2][0], out[3] = (double)num;
+        if (loss_mean) {  // the summary form: the two quotients and the mean loss as well
+            out[4] = red[0][0] / (double)num, out[5] = red[1][0] / (double)num;
+            *loss_mean = (float)(red[3][0] / (double)(B * T));
+        }
     }
 }
 
@@ -259,11 +272,30 @@ extern "C" int isg_softmax_xent_fwd(const void* logits, const int32_t* labels, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32)
         hipLaunchKernelGGL(xent_fwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), labels,
-                           weights, rows, cols, loss_rows, lse_rows, argmax_rows);
+                           weights, rows, cols, loss_rows, lse_rows, argmax_rows, nullptr, 0, nullptr);
     else
         hipLaunchKernelGGL(xent_fwd_kernel<__hip_bfloat16>, grid, block, 0, s,
                            static_cast<const __hip_bfloat16*>(logits), labels, weights, rows, cols, loss_rows,
-                           lse_rows, argmax_rows);
+                           lse_rows, argmax_rows, nullptr, 0, nullptr);
+    return isg::check_launch("xent_fwd_kernel");
+}
+
+extern "C" int isg_sequence_xent_fwd(const void* logits, const int32_t* targets_xy, int rows, int cols, int grid_side,
+                                     int dtype, float* loss_rows, float* lse_rows, int32_t* argmax_rows,
+                                     int32_t* labels_out, void* stream) {
+    int rc = check_rows("isg_sequence_xent_fwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && targets_xy && loss_rows && grid_side >= 1, ISG_EINVAL, "isg_sequence_xent_fwd: bad arguments");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(xent_fwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), nullptr, nullptr,
+                           rows, cols, loss_rows, lse_rows, argmax_rows, targets_xy, grid_side, labels_out);
+    else
+        hipLaunchKernelGGL(xent_fwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), nullptr, nullptr, rows, cols, loss_rows, lse_rows,
+                           argmax_rows, targets_xy, grid_side, labels_out);
     return isg::check_launch("xent_fwd_kernel");
 }
 
@@ -278,11 +310,31 @@ extern "C" int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ISG_F32)
         hipLaunchKernelGGL(xent_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), labels,
-                           lse_rows, row_scale, scale, rows, cols, static_cast<float*>(dlogits));
+                           lse_rows, row_scale, scale, rows, cols, static_cast<float*>(dlogits), nullptr);
     else
         hipLaunchKernelGGL(xent_bwd_kernel<__hip_bfloat16>, grid, block, 0, s,
                            static_cast<const __hip_bfloat16*>(logits), labels, lse_rows, row_scale, scale, rows, cols,
-                           static_cast<__hip_bfloat16*>(dlogits));
+                           static_cast<__hip_bfloat16*>(dlogits), nullptr);
+    return isg::check_launch("xent_bwd_kernel");
+}
+
+extern "C" int isg_softmax_xent_mean_bwd(const void* logits, const int32_t* labels, const float* lse_rows,
+                                         const float* upstream, int rows, int cols, int dtype, void* dlogits,
+                                         void* stream) {
+    int rc = check_rows("isg_softmax_xent_mean_bwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && labels && lse_rows && dlogits && upstream, ISG_EINVAL, "isg_softmax_xent_mean_bwd: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float scale = 1.0f / (float)rows;
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(xent_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), labels,
+                           lse_rows, nullptr, scale, rows, cols, static_cast<float*>(dlogits), upstream);
+    else
+        hipLaunchKernelGGL(xent_bwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), labels, lse_rows, nullptr, scale, rows, cols,
+                           static_cast<__hip_bfloat16*>(dlogits), upstream);
     return isg::check_launch("xent_bwd_kernel");
 }
 
@@ -354,6 +406,17 @@ extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets,
     ISG_REQUIRE(out4 && (B * T == 0 || (pred && targets && durations)), ISG_EINVAL,
                 "isg_sequence_metrics: null pointer");
     hipLaunchKernelGGL(sequence_metrics_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), pred, targets,
-                       durations, B, T, P, out4);
+                       durations, B, T, P, out4, nullptr, nullptr);
+    return isg::check_launch("sequence_metrics_kernel");
+}
+
+extern "C" int isg_sequence_summary(const int32_t* pred, const int32_t* targets, const int32_t* durations,
+                                    const float* loss_rows, int B, int T, int P, double* out6, float* loss_mean,
+                                    void* stream) {
+    ISG_REQUIRE(B >= 1 && T >= 1 && P >= 1, ISG_EINVAL, "isg_sequence_summary: bad shape B=%d T=%d P=%d", B, T, P);
+    ISG_REQUIRE(out6 && loss_mean && pred && targets && durations && loss_rows, ISG_EINVAL,
+                "isg_sequence_summary: null pointer");
+    hipLaunchKernelGGL(sequence_metrics_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), pred, targets,
+                       durations, B, T, P, out6, loss_rows, loss_mean);
     return isg::check_launch("sequence_metrics_kernel");
 }

@@ -22,7 +22,13 @@ def upload(array, device, dtype=None):
     points) go through pinned memory as an asynchronous copy, so the launches queued behind them keep flowing
     while the GPU is still busy with earlier work.  A pageable copy would block until the stream drains."""
     import numpy as np
-    arr = np.ascontiguousarray(np.asarray(array))
+    arr = np.asarray(array)
+    # a conversion the host can do itself happens before the copy (no converting launch on the device)
+    host_types = {torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32, torch.float64: np.float64,
+                  torch.uint8: np.uint8}
+    if dtype in host_types and arr.dtype != host_types[dtype]:
+        arr = arr.astype(host_types[dtype])
+    arr = np.ascontiguousarray(arr)
     device = torch.device(device)
     try:
         t = torch.from_numpy(arr)
@@ -63,6 +69,155 @@ def adam_tf_(param, m, v, grad, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_nor
                                 float(clip_norm) if clip_norm is not None else 0.0, _lib.current_stream())
     _lib.check(rc, "isg_adam_tf")
     _weights_epoch += 1
+
+
+# ---- derived weights -----------------------------------------------------------------------------------
+# Everything the kernels read that is a re-arrangement (and narrowing) of parameter values: the packed operand images
+# of the convolutions, tap tables, compute-type copies of dense weights.  A trainer whose parameters live in one flat
+# buffer (polyrnn Model) can own a DerivedWeights registry: the packing functions below record what they produced
+# while it is active, ``compile`` turns the recordings into index maps into the flat buffer (by packing a buffer of
+# index values with the very same kernels), and from then on ONE launch (isg_refresh_derived) brings all of it up to
+# date after an optimiser step, where each image used to be one or two launches of its own per step.
+_derived = None
+
+
+def active_derived():
+    return _derived
+
+
+class DerivedWeights:
+    def __init__(self, flat_param):
+        assert flat_param.dtype == torch.float32 and flat_param.is_contiguous()
+        self.flat = flat_param
+        self._recorded = {}   # key -> (object holding the tensors, attribute names, recompute(), parameters read)
+        self._compiled = {}   # key -> the same object once its tensors are views of the shared buffers
+        self._dirty = False   # recordings the maps do not cover yet
+        self._stamp = None
+        self._plan = None
+        self._depth = 0
+
+    def __enter__(self):
+        global _derived
+        self._depth += 1
+        self._outer = _derived if self._depth == 1 else self._outer
+        _derived = self
+        return self
+
+    def __exit__(self, *exc):
+        global _derived
+        self._depth -= 1
+        if self._depth == 0:
+            _derived = self._outer
+        return False
+
+    def owns(self, *tensors):
+        """Whether these are float32 views of the flat buffer (what the maps can describe)."""
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * 4
+        return all(t.dtype == torch.float32 and t.is_contiguous() and lo <= t.data_ptr() and
+                   t.data_ptr() + t.numel() * 4 <= hi for t in tensors)
+
+    def _now(self):
+        return (weights_epoch(), tuple(p._version for e in self._compiled.values() for p in e[3]))
+
+    def get(self, key):
+        """The recorded object under ``key`` with its tensors up to date, or None (not compiled yet: pack as usual).
+        A stream capture gets None as well: a captured graph packs for itself, so that a replay needs nothing
+        from outside the graph."""
+        e = self._compiled.get(key)
+        if e is None or torch.cuda.is_current_stream_capturing():
+            return None
+        self.ensure_fresh()
+        return e[0]
+
+    def record(self, key, obj, names, recompute, params):
+        if key not in self._compiled and not torch.cuda.is_current_stream_capturing():
+            self._recorded[key] = (obj, list(names), recompute, list(params))
+            self._dirty = True
+
+    def ensure_fresh(self):
+        """Refreshes every compiled tensor if a parameter changed since the last refresh (one launch).  Code that
+        replays a captured graph calls this before the replay: the graph holds no packing launches."""
+        if self._plan is not None and self._stamp != self._now():
+            self.refresh()
+
+    def compile(self):
+        """Turns what was recorded since the last call into maps (no-op when there is nothing new)."""
+        if not self._dirty:
+            return
+        self._dirty = False
+        entries = dict(self._compiled)
+        entries.update(self._recorded)
+        self._recorded = {}
+        flat = self.flat
+        n = flat.numel()
+        keep = flat.clone()
+        index = torch.arange(n, device=flat.device, dtype=torch.int64)
+        slots = [(key, name) for key, e in entries.items() for name in e[1] if getattr(e[0], name) is not None]
+        acc = {slot: None for slot in slots}
+        zero = {}
+        try:
+            for shift in (0, 8, 16, 24):
+                if shift and (n - 1) >> shift == 0:
+                    break
+                # the byte plus one, a value every compute type holds exactly; zero stays what padding looks like
+                flat.copy_((((index >> shift) & 255) + 1).to(torch.float32))
+                for e in entries.values():
+                    e[2]()
+                for key, name in slots:
+                    v = getattr(entries[key][0], name).detach().reshape(-1).to(torch.float32).round().to(torch.int64)
+                    z = v == 0
+                    if (key, name) in zero and not torch.equal(z, zero[(key, name)]):
+                        raise RuntimeError("derived weights: %r is not a pure re-arrangement of parameters" % (key,))
+                    zero[(key, name)] = z
+                    part = (v - 1).clamp_(min=0) << shift
+                    acc[(key, name)] = part if acc[(key, name)] is None else acc[(key, name)] + part
+        finally:
+            flat.copy_(keep)
+        maps16, maps32, ranges, views = [], [], [], []
+        off = {torch.bfloat16: 0, torch.float32: 0}
+        for key, name in slots:
+            t = getattr(entries[key][0], name)
+            m = torch.where(zero[(key, name)], torch.full_like(acc[(key, name)], -1), acc[(key, name)])
+            if int(m.max()) >= n:
+                raise RuntimeError("derived weights: %r reads outside the parameter buffer" % (key,))
+            k = m.numel()
+            run = k >= 4096 and t.dtype == torch.bfloat16 and len(ranges) < 4 and \
+                bool((m == m[0] + torch.arange(k, device=m.device)).all()) and int(m[0]) >= 0
+            if run:
+                ranges.append((int(m[0]), k, t))
+                continue
+            if t.dtype not in off:
+                raise RuntimeError("derived weights: %r holds %s" % (key, t.dtype))
+            pad = (-k) % 8  # every tensor starts on a 16-byte boundary of its shared buffer
+            m = torch.cat([m, torch.full([pad], -1, dtype=m.dtype, device=m.device)]) if pad else m
+            (maps16 if t.dtype == torch.bfloat16 else maps32).append(m)
+            views.append((key, name, t.dtype, off[t.dtype], k, list(t.shape)))
+            off[t.dtype] += k + pad
+        dev = flat.device
+        cat = lambda ms: torch.cat(ms).to(torch.int32) if ms else torch.zeros([0], dtype=torch.int32, device=dev)
+        plan = dict(map16=cat(maps16), map32=cat(maps32), ranges=ranges,
+                    out16=torch.zeros([off[torch.bfloat16]], dtype=torch.bfloat16, device=dev),
+                    out32=torch.zeros([off[torch.float32]], dtype=torch.float32, device=dev))
+        for key, name, dt, o, k, shape in views:
+            buf = plan["out16"] if dt == torch.bfloat16 else plan["out32"]
+            setattr(entries[key][0], name, buf[o:o + k].view(shape))
+        self._compiled, self._plan = entries, plan
+        self.refresh()
+
+    def refresh(self):
+        import ctypes
+        pl = self._plan
+        nr = len(pl["ranges"])
+        src = (ctypes.c_longlong * 4)(*[r[0] for r in pl["ranges"]])
+        cnt = (ctypes.c_longlong * 4)(*[r[1] for r in pl["ranges"]])
+        out = (ctypes.c_void_p * 4)(*[r[2].data_ptr() for r in pl["ranges"]])
+        rc = _lib.lib().isg_refresh_derived(_lib.ptr(self.flat), self.flat.numel(), _lib.ptr(pl["map16"]),
+                                            pl["map16"].numel(), _lib.ptr(pl["out16"]), _lib.ptr(pl["map32"]),
+                                            pl["map32"].numel(), _lib.ptr(pl["out32"]), nr, src, cnt, out,
+                                            _lib.current_stream())
+        _lib.check(rc, "isg_refresh_derived")
+        self._stamp = self._now()
 
 
 # ---- gradient sinks ------------------------------------------------------------------------------------
@@ -207,11 +362,16 @@ class PackedWeights:
         self.bias = bias.detach().to(torch.float32).contiguous()
         self.hist_table = torch.empty([9, self.hist, self.f, 4], dtype=torch.float32, device=w_x.device) \
             if self.hist else None
-        w_x32 = w_x.detach().to(torch.float32).contiguous()
-        w_h32 = w_h.detach().to(torch.float32).contiguous()
-        rc = lib.isg_convlstm_pack_weights(_lib.ptr(w_x32), _lib.ptr(w_h32), self.c, self.cs, self.hist, self.f,
-                                           dtype_code(dtype), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
-                                           _lib.ptr(self.hist_table), _lib.current_stream())
+        self._w_x, self._w_h = w_x, w_h
+        self.repack()
+
+    def repack(self):
+        """(Re)builds the images from the current parameter values."""
+        w_x32 = self._w_x.detach().to(torch.float32).contiguous()
+        w_h32 = self._w_h.detach().to(torch.float32).contiguous()
+        rc = _lib.lib().isg_convlstm_pack_weights(_lib.ptr(w_x32), _lib.ptr(w_h32), self.c, self.cs, self.hist, self.f,
+                                                  dtype_code(self.dtype), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
+                                                  _lib.ptr(self.hist_table), _lib.current_stream())
         _lib.check(rc, "isg_convlstm_pack_weights")
 
 
@@ -519,15 +679,26 @@ def conv_in_supported(w_hwio, dtype, device):
             _lib.lib().isg_conv_in_packed_elems(int(kh), int(cout)) > 0)
 
 
-def conv_in_pack(w_hwio):
+def conv_in_pack(w_hwio, out=None):
     """HWIO float weights [KS,KS,3,cout] -> the kernel's bf16 A-fragment image [KS * KXP/4, 64, 8] (output-channel
     rows padded to the 32 of an MFMA tile)."""
+    reg = _derived if out is None else None
+    key = ("conv_in", w_hwio.data_ptr(), tuple(w_hwio.shape))
+    if reg is not None:
+        e = reg.get(key)
+        if e is not None:
+            return e.out
     ks, cout = w_hwio.shape[0], w_hwio.shape[3]
     kxp = (ks + 3) // 4 * 4
     w = w_hwio.detach().float().contiguous()
-    out = torch.empty([ks * (kxp // 4), 64, 8], dtype=torch.bfloat16, device=w.device)
+    if out is None:
+        out = torch.empty([ks * (kxp // 4), 64, 8], dtype=torch.bfloat16, device=w.device)
     rc = _lib.lib().isg_conv_in_pack(_lib.ptr(w), int(ks), int(cout), _lib.ptr(out), _lib.current_stream())
     _lib.check(rc, "isg_conv_in_pack")
+    if reg is not None and reg.owns(w_hwio):
+        import types
+        ns = types.SimpleNamespace(out=out)
+        reg.record(key, ns, ["out"], lambda: conv_in_pack(w_hwio, out=ns.out), [w_hwio])
     return out
 
 
@@ -580,16 +751,27 @@ def conv32_supported(w_hwio, dtype, device):
             _lib.lib().isg_conv32_packed_elems(int(kh)) > 0)
 
 
-def conv32_pack(w_hwio, data_gradient=False):
+def conv32_pack(w_hwio, data_gradient=False, out=None):
     """HWIO float weights [KS,KS,C,C] (C = 32 or 16) -> the kernel's bf16 A-fragment image [KS*KS*C/16, 64, 8]
     (output-channel rows padded to the 32 of an MFMA tile); with ``data_gradient`` the image of the transposed
     convolution (flipped taps, channels swapped)."""
+    reg = _derived if out is None else None
+    key = ("conv32", w_hwio.data_ptr(), tuple(w_hwio.shape), bool(data_gradient))
+    if reg is not None:
+        e = reg.get(key)
+        if e is not None:
+            return e.out
     w = w_hwio.detach().float().contiguous()
     ks, c = w.shape[0], w.shape[2]
-    out = torch.empty([ks * ks * (c // 16), 64, 8], dtype=torch.bfloat16, device=w.device)
+    if out is None:
+        out = torch.empty([ks * ks * (c // 16), 64, 8], dtype=torch.bfloat16, device=w.device)
     rc = _lib.lib().isg_conv32_pack(_lib.ptr(w), int(ks), int(c), int(bool(data_gradient)), _lib.ptr(out),
                                     _lib.current_stream())
     _lib.check(rc, "isg_conv32_pack")
+    if reg is not None and reg.owns(w_hwio):
+        import types
+        ns = types.SimpleNamespace(out=out)
+        reg.record(key, ns, ["out"], lambda: conv32_pack(w_hwio, data_gradient, out=ns.out), [w_hwio])
     return out
 
 

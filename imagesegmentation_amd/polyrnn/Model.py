@@ -16,6 +16,7 @@ and ``self.end_token`` (see polyrnn/experiments.py).
 The recurrence runs in the HIP kernels of libisg (convLSTM.dynamic_rnn); the encoder convolutions and
 the dense head are plain torch ops (MIOpen / hipBLASLt).
 """
+import contextlib
 import json
 import math
 import os
@@ -193,6 +194,25 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+def _head_weights(dt, w, b, cache):
+    """The dense head's weights in the compute type: copies that are converted again when the weights change - by
+    the trainer's one refresh launch per step when a derived-weights registry is active (ops.DerivedWeights)."""
+    reg = ops.active_derived()
+    rkey = ("head", w.data_ptr(), b.data_ptr(), dt)
+    if reg is not None:
+        e = reg.get(rkey)
+        if e is not None:
+            return e.w, e.b
+    key = (dt, w._version, b._version, w.data_ptr(), ops.weights_epoch())
+    if cache.get("key") != key:
+        cache["key"], cache["w"], cache["b"] = key, w.detach().to(dt), b.detach().to(dt)
+        if reg is not None and dt == torch.bfloat16 and reg.owns(w.detach(), b.detach()):
+            import types
+            ns = types.SimpleNamespace(w=cache["w"], b=cache["b"])
+            reg.record(rkey, ns, ["w", "b"], lambda: (ns.w.copy_(w.detach()), ns.b.copy_(b.detach())), [w, b])
+    return cache["w"], cache["b"]
+
+
 class _DenseHead(torch.autograd.Function):
     """logits = flat @ W + b (reference polyrnn/History2LargeExperiment.py:48-50) with float32 master weights and
     activations in the compute type: the library GEMM runs in the compute type on copies of the weights that are
@@ -202,11 +222,7 @@ class _DenseHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, w, b, cache):
-        dt = flat.dtype
-        key = (dt, w._version, b._version, w.data_ptr(), ops.weights_epoch())
-        if cache.get("key") != key:
-            cache["key"], cache["w"], cache["b"] = key, w.detach().to(dt), b.detach().to(dt)
-        wc, bc = cache["w"], cache["b"]
+        wc, bc = _head_weights(flat.dtype, w, b, cache)
         ctx.save_for_backward(flat, wc)
         ctx.params = (w.detach(), b.detach())
         return torch.addmm(bc, flat, wc)
@@ -371,6 +387,11 @@ class Model:
         # parameters, gradients and both Adam moments each live in one flat buffer: one all-reduce, one norm,
         # one update launch
         self._flat_param = flatten_parameters_(self.trainable_variables)
+        #: images and copies derived from the parameters, brought up to date by one launch per optimiser step
+        #: (ops.DerivedWeights; ISG_NO_DERIVED=1: every consumer packs for itself, for A/B runs)
+        self._derived = ops.DerivedWeights(self._flat_param) \
+            if self.device.type == "cuda" and not os.environ.get("ISG_NO_DERIVED") else contextlib.nullcontext()
+        self._grad_one = None
         self._adam_m = torch.zeros_like(self._flat_param)
         self._adam_v = torch.zeros_like(self._flat_param)
         n = self._flat_param.numel()
@@ -485,11 +506,8 @@ class Model:
             logits = _DenseHead.apply(flat, w, b, self._head_cache)
         elif flat.dtype != w.dtype:
             # decode loops call the head once per step with unchanged weights: convert them once
-            cache = self._head_cache
-            key = (flat.dtype, w._version, b._version, w.data_ptr(), ops.weights_epoch())
-            if cache.get("key") != key:
-                cache["key"], cache["w"], cache["b"] = key, w.detach().to(flat.dtype), b.detach().to(flat.dtype)
-            logits = torch.addmm(cache["b"], flat, cache["w"])
+            wc, bc = _head_weights(flat.dtype, w, b, self._head_cache)
+            logits = torch.addmm(bc, flat, wc)
         else:
             logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
@@ -517,6 +535,9 @@ class Model:
         targets = self._to_dev(targets, torch.int32)
         dur = self._to_dev(durations, torch.int32)
         B, T, K = logits.shape
+        if logits.is_cuda:  # two launches: per-row pass (labels from the (x, y) targets), one summary launch
+            loss, m = decode.sequence_loss(logits, targets, dur, self.head_size)
+            return loss, dict(loss=loss.detach(), accuracy=m[4], avg_error=m[5], max_error=m[2])
         dense = targets[..., 0] * self.head_size + targets[..., 1]  # x-major (Model.py:39)
         pred = torch.empty([B * T], dtype=torch.int32, device=self.device)
         loss = decode.softmax_xent_mean(logits, dense, argmax_out=pred)
@@ -558,12 +579,14 @@ class Model:
         # the flat bucket (ops.grad_sinks) - the dense head's 9.8 M elements included; the zero fill is for what
         # autograd still accumulates itself (layers on library kernels), i.e. everything but the head's share.
         self._flat_grad[:self._early_reduce.offset].zero_()
-        with ops.grad_sinks(self._sinks, self._on_gradient_delivered) as sinks:
+        with self._derived, ops.grad_sinks(self._sinks, self._on_gradient_delivered) as sinks:
             logits, _ = self.forward(images, durations, histories, steps=steps)
             loss, metrics = self._loss_and_metrics(logits, durations, targets)
             if arm:
                 self._early_reduce.arm()
-            loss.backward()
+            if self._grad_one is None:
+                self._grad_one = torch.ones([], dtype=loss.dtype, device=loss.device)
+            loss.backward(gradient=self._grad_one)  # (a cached one: no fill launch per step)
         for p in (self.dense_kernel, self.dense_bias):
             if p.data_ptr() not in sinks.delivered:  # (cannot happen with the head above; kept as a guard)
                 raise RuntimeError("the dense head's gradient was not delivered to the flat bucket")
@@ -615,6 +638,8 @@ class Model:
             done = self._step_body(images, durations, histories, targets, arm=True)
         loss, metrics = done
         self._apply_gradients()
+        if isinstance(self._derived, ops.DerivedWeights):
+            self._derived.compile()  # (what this step packed for the first time joins the one refresh launch)
         self.loss = loss
         self.last_metrics = metrics
         return self.loss
@@ -625,7 +650,7 @@ class Model:
         self._add_summaries('train')
 
     def validate(self, images, durations, histories, targets, additional_feed_args={}):
-        with torch.no_grad():
+        with torch.no_grad(), self._derived:
             logits, _ = self.forward(images, durations, histories)
             loss, metrics = self._loss_and_metrics(logits, durations, targets)
         self.loss = loss
@@ -772,7 +797,8 @@ class Model:
         vt = ops.upload(vt_host, dev, torch.int32)
         nvt = ops.upload(nvt_host, dev, torch.int32)
         images_dev = self._to_dev(images, self.compute_dtype).contiguous()
-        predicted, durations, pts0, stepper = self._decode_body(images_dev, vt, nvt)
+        with self._derived:
+            predicted, durations, pts0, stepper = self._decode_body(images_dev, vt, nvt)
         self.decode_host_launches = self.max_timesteps * self.decode_launches_per_step
         self.rnn_final_state = stepper.state
         return predicted, durations, pts0, vt, nvt, self._iou_body(predicted, durations, pts0, vt, nvt)

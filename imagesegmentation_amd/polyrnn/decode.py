@@ -45,6 +45,57 @@ class _XentRows(torch.autograd.Function):
         return dz.reshape(ctx.shape).to(ctx.in_dtype), None, None, None
 
 
+class _SequenceLoss(torch.autograd.Function):
+    """Mean cross-entropy over every step of every sequence together with the step's masked metrics (reference
+    polyrnn/Model.py:44-54, 98-100) in two launches - the per-row pass and one summary launch that finishes the
+    mean and the quotients on the device - and a backward pass of one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, durations, prediction_size):
+        z, rows, cols = _rows(logits)
+        B, T = targets.shape[0], targets.shape[1]
+        tg = targets.to(torch.int32).contiguous()
+        dur = durations.to(torch.int32).contiguous()
+        dev = z.device
+        loss_rows = torch.empty([rows], dtype=torch.float32, device=dev)
+        lse = torch.empty([rows], dtype=torch.float32, device=dev)
+        pred = torch.empty([rows], dtype=torch.int32, device=dev)
+        lab = torch.empty([rows], dtype=torch.int32, device=dev)
+        rc = _lib.lib().isg_sequence_xent_fwd(_lib.ptr(z), _lib.ptr(tg), rows, cols, int(prediction_size),
+                                              dtype_code(z.dtype), _lib.ptr(loss_rows), _lib.ptr(lse), _lib.ptr(pred),
+                                              _lib.ptr(lab), _lib.current_stream())
+        _lib.check(rc, "isg_sequence_xent_fwd")
+        out6 = torch.empty([6], dtype=torch.float64, device=dev)
+        mean = torch.empty([], dtype=torch.float32, device=dev)
+        rc = _lib.lib().isg_sequence_summary(_lib.ptr(pred), _lib.ptr(tg), _lib.ptr(dur), _lib.ptr(loss_rows), B, T,
+                                             int(prediction_size), _lib.ptr(out6), _lib.ptr(mean), _lib.current_stream())
+        _lib.check(rc, "isg_sequence_summary")
+        ctx.save_for_backward(z, lab, lse)
+        ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
+        ctx.mark_non_differentiable(out6)
+        ctx.set_materialize_grads(False)  # (else a zero gradient for out6 is filled in on every backward pass)
+        return mean, out6
+
+    @staticmethod
+    def backward(ctx, dmean, _):
+        z, lab, lse = ctx.saved_tensors
+        rows, cols = z.shape
+        if dmean is None:
+            return None, None, None, None
+        up = dmean.to(torch.float32).contiguous()
+        dz = torch.empty_like(z)
+        rc = _lib.lib().isg_softmax_xent_mean_bwd(_lib.ptr(z), _lib.ptr(lab), _lib.ptr(lse), _lib.ptr(up), rows, cols,
+                                                  dtype_code(z.dtype), _lib.ptr(dz), _lib.current_stream())
+        _lib.check(rc, "isg_softmax_xent_mean_bwd")
+        return dz.reshape(ctx.shape).to(ctx.in_dtype), None, None, None
+
+
+def sequence_loss(logits, targets, durations, prediction_size):
+    """(mean loss, float64 [6] = correct, error sum, error max, live steps, accuracy, mean error); logits [B,T,K],
+    targets int [B,T,2] as (x, y) (class = x * prediction_size + y), durations int [B]."""
+    return _SequenceLoss.apply(logits, targets, durations, prediction_size)
+
+
 def softmax_xent_rows(logits, labels, weights=None, argmax_out=None):
     """Per-row sparse softmax cross-entropy (optionally times a per-row weight).  ``argmax_out``
     (int32, one per row) receives the first-maximum class of each row from the same pass."""

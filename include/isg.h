@@ -291,6 +291,18 @@ int isg_softmax_xent_fwd(const void* logits, const int32_t* labels, const float*
                          int dtype, float* loss_rows, float* lse_rows, int32_t* argmax_rows, void* stream);
 int isg_softmax_xent_bwd(const void* logits, const int32_t* labels, const float* lse_rows, const float* row_scale,
                          float scale, int rows, int cols, int dtype, void* dlogits, void* stream);
+
+/* The gradient of the MEAN of the per-row losses (reference polyrnn/Model.py:98-100, tf.reduce_mean over every step
+ * of every sequence): dlogits[r][c] = (softmax[r][c] - [c == label[r]]) * *upstream / rows, the gradient that arrives
+ * at the mean read from device memory (a float), so that no pass spreads it over the rows first. */
+int isg_softmax_xent_mean_bwd(const void* logits, const int32_t* labels, const float* lse_rows, const float* upstream,
+                              int rows, int cols, int dtype, void* dlogits, void* stream);
+
+/* isg_softmax_xent_fwd with the labels given as grid positions: label[r] = targets_xy[r][0] * grid_side +
+ * targets_xy[r][1] (x-major, reference polyrnn/Model.py:39; the end token (grid_side, 0) is class grid_side^2);
+ * labels_out (may be NULL) receives the labels, which the backward pass reads. */
+int isg_sequence_xent_fwd(const void* logits, const int32_t* targets_xy, int rows, int cols, int grid_side, int dtype,
+                          float* loss_rows, float* lse_rows, int32_t* argmax_rows, int32_t* labels_out, void* stream);
 int isg_argmax_rows(const void* logits, int rows, int cols, int dtype, int32_t* out_idx, void* stream);
 int isg_sample_rows(const void* logits, int rows, int cols, int dtype, unsigned long long seed,
                     unsigned long long row_offset, int32_t* out_idx, void* stream);
@@ -328,6 +340,13 @@ int isg_decode_step(const void* logits, int rows, int cols, int dtype, int P, in
 int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T, int P,
                          double* out4, void* stream);
 
+/* The same launch with the step's scalar summaries finished on the device (reference polyrnn/Model.py:44-54 and
+ * :98-100: three tf.reduce_mean / divisions): out6 = out4 followed by accuracy = out6[0] / out6[3] and
+ * avg_error = out6[1] / out6[3]; *loss_mean (device float) = the mean of loss_rows [B*T] (summed in double, in a
+ * fixed order), the un-masked mean the reference takes over every step of every sequence. */
+int isg_sequence_summary(const int32_t* pred, const int32_t* targets, const int32_t* durations, const float* loss_rows,
+                         int B, int T, int P, double* out6, float* loss_mean, void* stream);
+
 /* ---- optimiser ----------------------------------------------------------------------------------
  * tf.clip_by_global_norm + tf.train.AdamOptimizer as the reference applies them (polyrnn/Model.py:106-112;
  * polyrl/a3c/a3c.py:244-258 with clip 40) over flat float buffers of n values, one pass:
@@ -338,6 +357,18 @@ int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int3
  * grad is not modified.  All four buffers 16-byte aligned. */
 int isg_adam_tf(float* param, float* m, float* v, const float* grad, long long n, double lr_t, double beta1,
                 double beta2, double eps, const float* grad_norm, double clip_norm, void* stream);
+
+/* Everything the kernels read that is a re-arrangement (and narrowing) of parameter values - the packed operand
+ * images of isg_convlstm_pack_weights / isg_conv32_pack / isg_conv_in_pack, tap tables, compute-type copies of dense
+ * weights - refreshed from the flat float parameter buffer in ONE launch after an optimiser step, instead of one
+ * packing launch per image (the reference has no counterpart: TensorFlow reads its variables in place,
+ * polyrnn/Model.py:106-112 only updates them).  out_bf16[i] = bf16(src[map_bf16[i]]), out_f32[i] = src[map_f32[i]]
+ * (a negative map entry gives zero; the caller derives the maps once, e.g. by packing a buffer of index values);
+ * range r converts src[range_src[r] .. + range_n[r]) to bf16 at range_out[r] (n_ranges <= 4).  The maps are device
+ * int32 arrays, the range descriptions host arrays.  Every map entry must be < n_src (not checked on the device). */
+int isg_refresh_derived(const float* src, long long n_src, const int32_t* map_bf16, long long n_bf16, void* out_bf16,
+                        const int32_t* map_f32, long long n_f32, float* out_f32, int n_ranges, const long long* range_src,
+                        const long long* range_n, void* const* range_out, void* stream);
 
 /* ---- head pooling ----------------------------------------------------------------------------
  * Mean over non-overlapping k x k windows of x [N][H][W][F] -> out [N][H/k][W/k][F], same dtype,

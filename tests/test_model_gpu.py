@@ -691,3 +691,79 @@ def test_graph_replayed_training_step_equals_the_eager_step(name, dtype):
         assert torch.allclose(eager[0], graph[0], rtol=1e-4) and torch.allclose(eager[2], graph[2], atol=1e-4)
     assert eager[3] == graph[3] == 6
     assert bool((eager[0][-1] < eager[0][0]).item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["RNNConv", "EndTokenDeep_2", "History2Large"])
+def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(name, monkeypatch):
+    """ops.DerivedWeights: after the first training step every weight image, tap table and compute-type copy the
+    step used is a view of two shared buffers that ONE launch (isg_refresh_derived) fills from the flat parameter
+    buffer through index maps - derived by running the packing kernels on index values.  Checked: (1) after
+    further optimiser steps each refreshed tensor equals, bit for bit, what its own packing kernel writes from the
+    same parameters; (2) training with the registry is training without it (ISG_NO_DERIVED=1), bit for bit."""
+    from imagesegmentation_amd import data, ops
+    from imagesegmentation_amd.polyrnn import experiments
+    ds = data.PolygonDataset.synthetic(24, 28, 28, 10, 1 if name == "RNNConv" else 2, seed=9,
+                                       shape_mask_fn=oracle_raster.create_shape_mask, end_token=(name == "EndTokenDeep_2"))
+    runs = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("ISG_NO_DERIVED", "1")
+        model = experiments.make(name, image_size=28, compute_dtype=torch.bfloat16, device="cuda:0", seed=5,
+                                 learning_rate=1e-3)
+        np.random.seed(77)
+        losses = []
+        for _ in range(4):
+            d, images, pts, t, _ = ds.get_batch_points(8)
+            losses.append(model.train_step(images, d, pts, t).clone())
+        runs[off] = (torch.stack(losses), model._flat_param.clone())
+        if not off:
+            reg = model._derived
+            assert isinstance(reg, ops.DerivedWeights) and reg._plan is not None and not reg._recorded
+            # one LSTM entry per layer, the head, the first encoder layer, two images per further encoder layer
+            assert len(reg._compiled) == len(model.rnn.cells) + 1 + 1 + 2 * (len(model.encoder) - 1)
+            reg.ensure_fresh()
+            for key, (obj, names, recompute, _) in reg._compiled.items():
+                before = {n: getattr(obj, n).clone() for n in names if getattr(obj, n) is not None}
+                for n in before:
+                    getattr(obj, n).zero_()
+                recompute()  # the entry's own packing kernels, into the same tensors
+                for n, ref in before.items():
+                    got = getattr(obj, n)
+                    assert torch.equal(got.view(torch.int16) if got.dtype == torch.bfloat16 else got,
+                                       ref.view(torch.int16) if ref.dtype == torch.bfloat16 else ref), (key, n)
+    assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1], runs[True][1])
+    assert bool((runs[False][0][-1] < runs[False][0][0]).item())
+
+
+@pytest.mark.gpu
+def test_refresh_after_a_checkpoint_restore_and_in_place_edits():
+    """The registry notices parameter changes it did not make: ops.note_weights_changed() (checkpoint restore into
+    the flat buffer) and in-place edits of a parameter that torch's version counter sees."""
+    from imagesegmentation_amd import data, ops
+    from imagesegmentation_amd.polyrnn import experiments
+    ds = data.PolygonDataset.synthetic(16, 28, 28, 10, 2, seed=2, shape_mask_fn=oracle_raster.create_shape_mask)
+    np.random.seed(1)
+    d, images, pts, t, _ = ds.get_batch_points(8)
+    model = experiments.make("History2Large", image_size=28, device="cuda:0", seed=5)
+    model.train_step(images, d, pts, t)
+    model.train_step(images, d, pts, t)
+
+    def valid_loss(m):
+        m.validate(images, d, pts, t)
+        return m.loss.item()
+
+    base = valid_loss(model)
+    keep = model._flat_param.clone()
+    with torch.no_grad():
+        model._flat_param.mul_(0.5)
+    ops.note_weights_changed()
+    halved = valid_loss(model)
+    assert halved != base
+    with torch.no_grad():
+        model._flat_param.copy_(keep)
+    ops.note_weights_changed()
+    assert valid_loss(model) == base
+    with torch.no_grad():
+        model.rnn.cells[0].input_to_state_kernel.mul_(0.0)  # (a tracked in-place edit, no epoch change)
+    assert valid_loss(model) != base
