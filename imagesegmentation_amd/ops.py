@@ -95,6 +95,7 @@ class DerivedWeights:
         self._stamp = None
         self._plan = None
         self._depth = 0
+        self.generation = 0   # counts compiles that moved the tensors
 
     def __enter__(self):
         global _derived
@@ -122,12 +123,14 @@ class DerivedWeights:
 
     def get(self, key):
         """The recorded object under ``key`` with its tensors up to date, or None (not compiled yet: pack as usual).
-        A stream capture gets None as well: a captured graph packs for itself, so that a replay needs nothing
-        from outside the graph."""
+        Under a stream capture the tensors are handed out as they are - the captured graph then holds no packing
+        launches, and whoever replays it calls ``ensure_fresh`` first and drops the graph when ``generation`` has
+        moved (a later ``compile`` moves every tensor to new shared buffers)."""
         e = self._compiled.get(key)
-        if e is None or torch.cuda.is_current_stream_capturing():
+        if e is None:
             return None
-        self.ensure_fresh()
+        if not torch.cuda.is_current_stream_capturing():
+            self.ensure_fresh()
         return e[0]
 
     def record(self, key, obj, names, recompute, params):
@@ -203,6 +206,7 @@ class DerivedWeights:
             buf = plan["out16"] if dt == torch.bfloat16 else plan["out32"]
             setattr(entries[key][0], name, buf[o:o + k].view(shape))
         self._compiled, self._plan = entries, plan
+        self.generation += 1
         self.refresh()
 
     def refresh(self):

@@ -264,10 +264,11 @@ class _AvgPool(torch.autograd.Function):
 
 class _DecodeGraph:
     """The decode loop of one (model, batch size) captured as a HIP graph: inputs are copied into the graph's own
-    buffers, one launch replays encoder + weight packing + T x (cells, head, decode step) + the assembly and
-    rasterisation of the predicted polygons, and the results are read from its buffers.  The packing kernels are
-    part of the graph and read the master weights where they live (the flat parameter buffer), so a replay after an
-    optimiser step decodes with the new weights.  The graph's buffers are overwritten by the next replay: what is
+    buffers, one launch replays encoder + T x (cells, head, decode step) + the assembly and rasterisation of the
+    predicted polygons, and the results are read from its buffers.  The weight images it reads are the model's shared
+    buffers (ops.DerivedWeights), refreshed by one launch ahead of a replay when the weights have changed (without
+    that registry the packing kernels are part of the graph and read the master weights where they live), so a
+    replay after an optimiser step decodes with the new weights.  The graph's buffers are overwritten by the next replay: what is
     handed out of ``run`` are copies, except the recurrent state (a view that lives until then)."""
 
     def __init__(self, model, images_dev, vt, nvt):
@@ -275,12 +276,16 @@ class _DecodeGraph:
         self.vt, self.nvt = vt.clone(), nvt.clone()
 
         def body():
-            predicted, durations, pts0, stepper = model._decode_body(self.images, self.vt, self.nvt)
+            with model._derived:
+                predicted, durations, pts0, stepper = model._decode_body(self.images, self.vt, self.nvt)
             return predicted, durations, pts0, stepper, model._iou_body(predicted, durations, pts0, self.vt, self.nvt)
         # one eager pass first: library handles and workspaces come into being outside the capture
         body()
+        #: the weight images the loop reads live in the model's shared buffers (ops.DerivedWeights) and are brought
+        #: up to date before a replay; this graph is good for as long as they stay where they are
+        self.generation = model._derived_generation()
         torch.cuda.synchronize()
-        # everything cached from the weights is rebuilt inside the capture, so that the rebuild is part of the graph
+        # anything else cached from the weights is rebuilt inside the capture, so that the rebuild is part of the graph
         self._drop_weight_caches(model)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
@@ -317,8 +322,9 @@ class _StepGraph:
     launches of a few microseconds each and the host cannot issue them as fast as the GPU retires them; replayed
     as a graph they cost one launch.  Inputs are copied into the graph's buffers; the gradients land in the
     model's flat bucket (the backward passes write there, ops.grad_sinks); the exchange between ranks, the clip
-    and Adam follow outside the graph.  Weight packing and the head's weight copies are part of the graph and read
-    the master weights where they live, so every replay uses the current weights."""
+    and Adam follow outside the graph.  The weight images and the head's weight copies are the model's shared
+    buffers (ops.DerivedWeights), refreshed by one launch ahead of a replay when the weights have changed; without
+    that registry the packing launches are part of the graph and read the master weights where they live."""
 
     def __init__(self, model, images, durations, points, targets, steps):
         dev = model.device
@@ -329,6 +335,7 @@ class _StepGraph:
         self.steps = steps
         self.load(images, durations, points, targets)
         model._step_body(self.images, self.durations, self.points, self.targets, steps)  # eager: workspaces, handles
+        self.generation = model._derived_generation()  # (see _DecodeGraph)
         torch.cuda.synchronize()
         _DecodeGraph._drop_weight_caches(model)
         self.graph = torch.cuda.CUDAGraph()
@@ -592,6 +599,23 @@ class Model:
                 raise RuntimeError("the dense head's gradient was not delivered to the flat bucket")
         return loss.detach(), metrics
 
+    def _derived_generation(self):
+        """Compiles what the registry of derived weights recorded and says where its tensors live now (a count of
+        the moves; None without a registry).  A captured graph remembers the answer."""
+        if not isinstance(self._derived, ops.DerivedWeights):
+            return None
+        self._derived.compile()
+        return self._derived.generation
+
+    def _graph_usable(self, graph):
+        """Before a replay: the graph still reads the right buffers, and they hold the current weights."""
+        if not isinstance(self._derived, ops.DerivedWeights):
+            return True
+        if graph.generation != self._derived.generation:
+            return False
+        self._derived.ensure_fresh()
+        return True
+
     def _encoder_is_native(self):
         """Whether every encoder layer runs on this library's kernels (bf16; first layer 3 -> 16 / 32 channels, the
         others 16 -> 16 / 32 -> 32): no vendor convolution anywhere in the step."""
@@ -616,6 +640,9 @@ class Model:
             steps = int(min(max(int(d.max()) if d.size else 0, 0), self.max_timesteps))
         key = (tuple(images.shape), tuple(points.shape), tuple(np.shape(targets)), steps)
         graph = self._step_graph_cache.get(key)
+        if graph is not None and not self._graph_usable(graph):
+            graph = None
+            del self._step_graph_cache[key]
         if graph is None:
             if len(self._step_graph_cache) >= 2 * self.max_timesteps + 2:
                 self._step_graph_cache.pop(next(iter(self._step_graph_cache)))
@@ -760,6 +787,9 @@ class Model:
             return None
         key = (B, tuple(image_shape))
         graph = self._decode_graph_cache.get(key)
+        if graph is not None and not self._graph_usable(graph):
+            graph = None
+            del self._decode_graph_cache[key]
         if graph is None:
             if len(self._decode_graph_cache) >= 4:  # (each holds its buffers: keep a handful of batch sizes)
                 self._decode_graph_cache.pop(next(iter(self._decode_graph_cache)))
