@@ -49,6 +49,7 @@ SIGNATURES = {
     "isg_conv_in_wgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_conv32_packed_elems": (_ll, [_int]),
     "isg_conv32_pack": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "isg_conv32_pack_padded": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_conv32": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
     "isg_conv32_wgrad_workspace_bytes": (_ll, [_int]),
     "isg_conv32_wgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),

@@ -257,8 +257,9 @@ namespace {
 
 // [KS*KS*C/16][64][8]: element [tap * (C/16) + q][32 kg + m][j] = A[tap][m][16 q + 8 kg + j]; forward
 // A[tap][m][k] = w[ty][tx][k][m], data gradient A[tap][m][k] = w[KS-1-ty][KS-1-tx][m][k]; rows m >= C are zero.
+// (cin < C, forward image only: weights [KS][KS][cin][C] of a layer whose input is padded to C channels with zeros)
 __global__ __launch_bounds__(256) void conv_square_pack_kernel(const float* __restrict__ w, int KS, int C, int data_gradient,
-                                                               __bf16* __restrict__ out, int total) {
+                                                               __bf16* __restrict__ out, int total, int cin) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(256) void conv_square_pack_kernel(const float* __re
     const int m = lane & 31, k = 16 * q + 8 * (lane >> 5) + j;
     const int ty = tap / KS, tx = tap - ty * KS;
     float v = 0.0f;
-    if (m < C)
-        v = data_gradient ? w[(((KS - 1 - ty) * KS + (KS - 1 - tx)) * C + m) * C + k] : w[((ty * KS + tx) * C + k) * C + m];
+    if (m < C && k < cin)
+        v = data_gradient ? w[(((KS - 1 - ty) * KS + (KS - 1 - tx)) * C + m) * C + k] : w[((ty * KS + tx) * cin + k) * C + m];
     out[idx] = (__bf16)v;
 }
 
@@ -294,7 +295,17 @@ extern "C" int isg_conv32_pack(const float* w, int KS, int C, int data_gradient,
     ISG_REQUIRE((KS == 3 || KS == 5) && (C == 16 || C == 32), ISG_EINVAL, "isg_conv32_pack: 3 x 3 or 5 x 5 taps, 16 or 32 channels");
     const int total = KS * KS * (C / 16) * 512;
     hipLaunchKernelGGL(conv_square_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, KS,
-                       C, data_gradient, static_cast<__bf16*>(wimg), total);
+                       C, data_gradient, static_cast<__bf16*>(wimg), total, C);
+    return isg::check_launch("conv_square_pack_kernel");
+}
+
+extern "C" int isg_conv32_pack_padded(const float* w, int KS, int C, int cin, void* wimg, void* stream) {
+    ISG_REQUIRE(w && wimg, ISG_EINVAL, "isg_conv32_pack_padded: null argument");
+    ISG_REQUIRE((KS == 3 || KS == 5) && (C == 16 || C == 32) && cin >= 1 && cin <= C, ISG_EINVAL,
+                "isg_conv32_pack_padded: 3 x 3 or 5 x 5 taps, 16 or 32 output channels, 1..C input channels");
+    const int total = KS * KS * (C / 16) * 512;
+    hipLaunchKernelGGL(conv_square_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, KS,
+                       C, 0, static_cast<__bf16*>(wimg), total, cin);
     return isg::check_launch("conv_square_pack_kernel");
 }
 

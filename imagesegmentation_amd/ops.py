@@ -779,6 +779,36 @@ def conv32_pack(w_hwio, data_gradient=False, out=None):
     return out
 
 
+def conv32_pack_padded(w_hwio, out=None):
+    """HWIO float weights [KS,KS,cin,C] with cin < C (C = 32 or 16) -> the forward image of ``conv32`` for an input
+    padded to C channels with zeros."""
+    reg = _derived if out is None else None
+    key = ("conv32_padded", w_hwio.data_ptr(), tuple(w_hwio.shape))
+    if reg is not None:
+        e = reg.get(key)
+        if e is not None:
+            return e.out
+    w = w_hwio.detach().float().contiguous()
+    ks, cin, c = w.shape[0], w.shape[2], w.shape[3]
+    if out is None:
+        out = torch.empty([ks * ks * (c // 16), 64, 8], dtype=torch.bfloat16, device=w.device)
+    rc = _lib.lib().isg_conv32_pack_padded(_lib.ptr(w), int(ks), int(c), int(cin), _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_conv32_pack_padded")
+    if reg is not None and reg.owns(w_hwio):
+        import types
+        ns = types.SimpleNamespace(out=out)
+        reg.record(key, ns, ["out"], lambda: conv32_pack_padded(w_hwio, out=ns.out), [w_hwio])
+    return out
+
+
+def conv32_padded_supported(w_hwio, dtype, device):
+    """Whether ``conv32`` takes this layer on an input padded with zero channels: square 3 x 3 or 5 x 5, 32 or 16
+    output channels, fewer input channels than that, bf16."""
+    kh, kw, cin, cout = w_hwio.shape
+    return (kh == kw and cin < cout and cout in (16, 32) and dtype == torch.bfloat16 and device.type == "cuda" and
+            _lib.lib().isg_conv32_packed_elems(int(kh)) > 0)
+
+
 def conv32(x, wimg, bias, ks, relu):
     B, H, W, c = x.shape
     assert c in (16, 32) and x.dtype == torch.bfloat16 and x.is_contiguous()

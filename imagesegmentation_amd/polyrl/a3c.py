@@ -19,17 +19,18 @@ the per-rollout losses are averaged, and ranks exchange ONE all-reduce of the fl
 The env adapter ``action -> (a // P, a % P)`` (x-major, as the class index of polyrnn/Model.py:39) is
 this build's; the reference hands ``action.argmax()`` to an environment that expects a point.
 """
+import contextlib
 import math
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import parallel
+from .. import ops, parallel
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, WideStepper, dynamic_rnn, glorot_uniform_
 from ..optim import FlatAdam
 from ..polyrnn import decode
-from ..polyrnn.Model import conv2d_same_relu
+from ..polyrnn.Model import _DenseHead, _head_weights, conv2d_same_relu
 
 
 def discount(x, gamma):
@@ -128,6 +129,7 @@ class LSTMPolicy:
         self.action_bias = torch.nn.Parameter(torch.zeros([self.ac_space], device=self.device))
         self.value_kernel = torch.nn.Parameter(_dense_init((flat, 1), self.device, gen))
         self.value_bias = torch.nn.Parameter(torch.zeros([1], device=self.device))
+        self._head_caches = ({}, {})  # compute-type copies of the two dense heads' weights
         self._sample_calls = 0
         self._base_seed = seed  # weights above come from `seed` itself: equal on every rank
         self._rank_seed = None
@@ -181,11 +183,24 @@ class LSTMPolicy:
         N, T = x.shape[0], x.shape[1]
         feats = self._encode(x.reshape((N * T,) + tuple(x.shape[2:]))).reshape((N, T) + tuple(x.shape[2:4]) + (32,))
         out, final = dynamic_rnn(self.lstm, feats, initial_state=LSTMStateTuple(*state), time_major=False)
-        flat = out.reshape(N * T, -1)
+        logits, vf = self._heads(out.reshape(N * T, -1))
+        return logits.reshape(N, T, -1), vf.reshape(N, T), final
+
+    def _heads(self, flat):
+        """flat [R, H W F] -> (logits float32 [R, K], value float32 [R]): two library GEMMs in the compute type on
+        copies of the weights that are converted once per optimiser step (reference polyrl/a3c/model.py:38-41)."""
         dt = flat.dtype
-        logits = torch.addmm(self.action_bias.to(dt), flat, self.action_kernel.to(dt)).float().reshape(N, T, -1)
-        vf = torch.addmm(self.value_bias.to(dt), flat, self.value_kernel.to(dt)).float().reshape(N, T)
-        return logits, vf, final
+        heads = ((self.action_kernel, self.action_bias), (self.value_kernel, self.value_bias))
+        out = []
+        for (w, b), cache in zip(heads, self._head_caches):
+            if torch.is_grad_enabled() and flat.is_cuda and (flat.requires_grad or w.requires_grad):
+                out.append(_DenseHead.apply(flat, w, b, cache).float())
+            elif dt != w.dtype:
+                wc, bc = _head_weights(dt, w, b, cache)
+                out.append(torch.addmm(bc, flat, wc).float())
+            else:
+                out.append(torch.addmm(b.detach(), flat, w.detach()))
+        return out[0], out[1][:, 0]
 
     def act(self, ob, c, h):
         """One step for N environments: (action index int64 [N], value [N], c, h)
@@ -206,10 +221,7 @@ class LSTMPolicy:
         value [N]).  Same arithmetic and the same sampling stream as ``act``."""
         with torch.no_grad():
             feats = self._encode(ob)
-            flat = stepper.step(feats).reshape(ob.shape[0], -1)
-            dt = flat.dtype
-            logits = torch.addmm(self.action_bias.to(dt), flat, self.action_kernel.to(dt)).float()
-            vf = torch.addmm(self.value_bias.to(dt), flat, self.value_kernel.to(dt)).float()[:, 0]
+            logits, vf = self._heads(stepper.step(feats).reshape(ob.shape[0], -1))
             self._sample_calls += 1
             a = decode.sample_rows(logits.contiguous(), seed=self._seed * 1000003 + self._sample_calls)
         return a.long(), vf
@@ -234,6 +246,9 @@ class A3C:
         self.network = self.local_network = policy  # one copy: the sync of :251,281 is the identity
         self.gamma, self.lambda_ = gamma, lambda_
         self.opt = FlatAdam(policy.var_list, learning_rate=learning_rate, clip_norm=40.0, process_group=process_group)
+        #: images and copies derived from the parameters, brought up to date by one launch per update
+        #: (ops.DerivedWeights) instead of once per acting step
+        self.derived = ops.DerivedWeights(self.opt.flat_param) if self.opt.flat_param.is_cuda else contextlib.nullcontext()
         self.global_step = 0
         self.local_steps = 0
         self.last = {}
@@ -268,6 +283,13 @@ class A3C:
         return dict(si=obs, a=actions, values=values, rewards=rewards, lengths=lengths, terminal=env.done.clone())
 
     def process(self, images=None, polygons=None):
+        with self.derived:
+            batch = self._process(images, polygons)
+        if isinstance(self.derived, ops.DerivedWeights):
+            self.derived.compile()
+        return batch
+
+    def _process(self, images=None, polygons=None):
         pi = self.local_network
         batch = self.pull_batch(images, polygons)
         N, T = batch["a"].shape

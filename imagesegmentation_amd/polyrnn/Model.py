@@ -108,6 +108,28 @@ class _Conv32(torch.autograd.Function):
         return dx, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
 
 
+class _Conv32Padded(torch.autograd.Function):
+    """A layer with fewer input channels than its 32 (16) filters on the isg_conv32 (isg_conv16) kernels: the input is
+    padded with zero channels (reference polyrl/a3c/model.py:19-20, whose first layer sees 3 image channels + the
+    history frames).  The input gets no gradient (it is an observation)."""
+
+    @staticmethod
+    def forward(ctx, x, w_hwio, bias):
+        ks, cin, c = w_hwio.shape[0], w_hwio.shape[2], w_hwio.shape[3]
+        xp = F.pad(x, (0, c - cin)).contiguous()
+        y = ops.conv32(xp, ops.conv32_pack_padded(w_hwio), bias.detach().float().contiguous(), ks, relu=True)
+        ctx.save_for_backward(xp, y)
+        ctx.ks, ctx.cin, ctx.dtypes = ks, cin, (w_hwio.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, y = ctx.saved_tensors
+        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), y)
+        dw = ops.conv32_wgrad(xp, dz, ctx.ks)[:, :, :ctx.cin]
+        return None, dw.to(ctx.dtypes[0]), dbias.to(ctx.dtypes[1])
+
+
 class _EncoderChain(torch.autograd.Function):
     """A whole encoder of hand-written layers - the first on the isg_conv_in kernels, the others on isg_conv32 /
     isg_conv16 - as one autograd node (reference polyrnn/History2LargeExperiment.py:15-22,
@@ -175,6 +197,8 @@ def conv2d_same_relu(x_nhwc, w_hwio, b, dtype):
         return _ConvIn.apply(x_nhwc, w_hwio, b)
     if x_nhwc.dtype == dtype and ops.conv32_supported(w_hwio, dtype, x_nhwc.device):
         return _Conv32.apply(x_nhwc, w_hwio, b)
+    if x_nhwc.dtype == dtype and not x_nhwc.requires_grad and ops.conv32_padded_supported(w_hwio, dtype, x_nhwc.device):
+        return _Conv32Padded.apply(x_nhwc, w_hwio, b)
     x = x_nhwc.permute(0, 3, 1, 2)  # NCHW view of channels-last memory
     pt, pl = (kh - 1) // 2, (kw - 1) // 2
     if kh % 2 == 0 or kw % 2 == 0:

@@ -443,6 +443,10 @@ long long isg_conv32_packed_elems(int KS);
 /* The image of isg_conv32 / isg_conv16 (C = 32 / 16: [KS*KS*C/16][64][8], element [tap * C/16 + q][32 kg + m][j], rows
  * m >= C zero) from float HWIO weights w [KS][KS][C][C], forward or (data_gradient != 0) data gradient; one launch. */
 int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg, void* stream);
+/* The forward image of a layer with cin < C input channels run on isg_conv32 / isg_conv16 with its input padded to C
+ * channels by zeros (reference polyrl/a3c/model.py:19-20: the first of four 3 x 3, 32-filter layers sees the 3 image
+ * channels + the history frames): w float [KS][KS][cin][C], the image's k >= cin entries are zero. */
+int isg_conv32_pack_padded(const float* w, int KS, int C, int cin, void* wimg, void* stream);
 int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
                void* stream);
 long long isg_conv32_wgrad_workspace_bytes(int KS);
