@@ -23,12 +23,14 @@ from . import ops
 LSTMStateTuple = collections.namedtuple("LSTMStateTuple", ("c", "h"))
 
 
-def glorot_uniform_(tensor):
-    """TensorFlow's default variable initializer for get_variable (glorot uniform) on an HWIO kernel."""
+def glorot_uniform_(tensor, generator=None):
+    """TensorFlow's default variable initializer for get_variable (glorot uniform) on an HWIO kernel.  ``generator``:
+    the stream the numbers come from (a trainer whose ranks must hold the same weights passes its seeded one;
+    None = torch's global stream)."""
     kh, kw, cin, cout = tensor.shape
     limit = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
     with torch.no_grad():
-        return tensor.uniform_(-limit, limit)
+        return tensor.uniform_(-limit, limit, generator=generator)
 
 
 def _pad_channels(x, cs):
@@ -481,6 +483,12 @@ class WideStepper:
                 self.Cst[g][0].copy_(c0[..., Fh * g:Fh * g + Fh])
                 self.H[g][0].copy_(h0[..., Fh * g:Fh * g + Fh])
 
+    def reset(self):
+        """Back to the zero state, in place (the buffers keep their addresses: a captured graph may hold them)."""
+        for t in self.H + self.Cst:
+            t.zero_()
+        self.cur = 0
+
     @property
     def state(self):
         """(c, h) of the whole cell, joined (a copy)."""
@@ -665,23 +673,40 @@ def _wide_groups(cell, C):
     columns are the group's columns of each j|i|f|o block.  The groups' packed weight images are cached until
     the weights change."""
     params = (cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias)
-    key = tuple((p.data_ptr(), p._version) for p in params) + (cell.compute_dtype, ops.weights_epoch())
+    Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
+    reg = ops.active_derived()
+    rkeys = [("wide",) + tuple(p.data_ptr() for p in params) + (dt, C, s) for s in range(F // Fh)]
+    if reg is not None:  # a trainer that refreshes every derived tensor in one launch per optimiser step
+        hit = [reg.get(k) for k in rkeys]
+        if all(h is not None for h in hit):
+            return [(h.cols, h) for h in hit]
+    key = tuple((p.data_ptr(), p._version) for p in params) + (dt, ops.weights_epoch())
     cached = getattr(cell, "_wide_cache", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
     cw = C + F - Fh
     if cw > 64 - Fh:
         raise NotImplementedError("a %d-filter cell takes at most %d input channels" % (F, 64 - F))
+
+    def group_weights(cols):
+        w_h_cols = params[1].detach().index_select(3, cols)
+        w_x = torch.cat([params[0].detach().index_select(3, cols), w_h_cols[:, :, Fh:]], dim=2).contiguous()
+        return w_x, w_h_cols[:, :, :Fh].contiguous(), params[2].detach().index_select(0, cols)
+
     groups = []
     with torch.no_grad():
         for s in range(F // Fh):
             cols = torch.cat([torch.arange(g * F + Fh * s, g * F + Fh * s + Fh) for g in range(4)]).to(params[0].device)
-            w_h_cols = params[1].index_select(3, cols)
-            w_x = torch.cat([params[0].index_select(3, cols), w_h_cols[:, :, Fh:]], dim=2).contiguous()
-            packed = ops.PackedWeights(w_x, w_h_cols[:, :, :Fh].contiguous(), params[2].index_select(0, cols),
-                                       ops.padded_channels(cw, dt), dt)
+            packed = ops.PackedWeights(*group_weights(cols), ops.padded_channels(cw, dt), dt)
+            packed.cols = cols
             groups.append((cols, packed))
+            if reg is not None and reg.owns(*[p.detach() for p in params]):
+                def again(packed=packed, cols=cols):  # the group's tensors from the parameters as they are now
+                    with torch.no_grad():
+                        packed._w_x, packed._w_h, bias = group_weights(cols)
+                        packed.bias.copy_(bias)
+                        packed.repack()
+                reg.record(rkeys[s], packed, ["fwd", "dgrad", "bias"], again, params)
     cell._wide_cache = (key, groups)
     return groups
 

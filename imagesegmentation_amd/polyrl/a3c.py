@@ -21,6 +21,7 @@ this build's; the reference hands ``action.argmax()`` to an environment that exp
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -119,7 +120,8 @@ class LSTMPolicy:
             w.copy_((torch.rand(w.shape, device=self.device, generator=gen) * 2 - 1) * limit)
             self.convs.append((torch.nn.Parameter(w), torch.nn.Parameter(torch.zeros([32], device=self.device))))
             cin = 32
-        init = lambda t: t.copy_(glorot_uniform_(torch.empty_like(t)))
+        # (from the policy's own seeded stream: every rank of a data-parallel run must start from the same weights)
+        init = lambda t: t.copy_(glorot_uniform_(torch.empty_like(t), generator=gen))
         self.lstm = ConvLSTMCell(shape=[H, W], filters=self.filters, kernel=[3, 3], initializer=init,
                                  compute_dtype=compute_dtype, device=self.device)
         self.lstm.build(cin, self.device)
@@ -226,6 +228,18 @@ class LSTMPolicy:
             a = decode.sample_rows(logits.contiguous(), seed=self._seed * 1000003 + self._sample_calls)
         return a.long(), vf
 
+    def act_step_xy(self, ob, stepper, row_offset_dev, grid_side):
+        """``act_step`` for a loop that may be captured as a graph: the action arrives as int32 (x, y) [N, 2] from the
+        sampling launch itself and the sampling stream's position is a device counter (int64 scalar, advanced here by
+        N), so that a replay draws new numbers.  Returns ((x, y), value [N])."""
+        with torch.no_grad():
+            feats = self._encode(ob)
+            logits, vf = self._heads(stepper.step(feats).reshape(ob.shape[0], -1))
+            xy = decode.sample_actions(logits.contiguous(), seed=self._seed, grid_side=grid_side,
+                                       row_offset_dev=row_offset_dev)
+            row_offset_dev += ob.shape[0]
+        return xy, vf
+
     def value(self, ob, c, h):
         with torch.no_grad():
             return self.forward(ob[:, None], (c, h))[1][:, 0]
@@ -252,6 +266,11 @@ class A3C:
         self.global_step = 0
         self.local_steps = 0
         self.last = {}
+        #: True: the acting loop of a 32-filter policy (T x (encoder, cell, heads, sampling, environment step,
+        #: terminal IoU)) is captured as one HIP graph and replayed (the loop is a few hundred launches of a few
+        #: microseconds each: the host cannot issue them as fast as the GPU retires them)
+        self.rollout_graph = self.opt.flat_param.is_cuda and not os.environ.get("ISG_NO_ROLLOUT_GRAPH")
+        self._rollout = None
 
     def pull_batch(self, images=None, polygons=None):
         """Every environment from reset to its terminal step or the step limit."""
@@ -259,8 +278,9 @@ class A3C:
         N, T, P = env.num_envs, self.TIMESTEP_LIMIT, env.size
         dev = env.device
         state = env.reset(images=images, polygons=polygons)
-        rec = pi.stepper(N) if pi.filters > 16 else None  # the recurrent state, or (c, h) through ``act``
-        c, h = pi.get_initial_features(N) if rec is None else (None, None)
+        if pi.filters > 16 and dev.type == "cuda":
+            return self._pull_batch_stepper(state)
+        c, h = pi.get_initial_features(N)
         obs = torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev)
         actions = torch.zeros([N, T], dtype=torch.int64, device=dev)
         values = torch.zeros([N, T], dtype=torch.float32, device=dev)
@@ -271,16 +291,80 @@ class A3C:
             # its later steps fall outside its length
             active = ~env.done
             obs[:, t] = state
-            if rec is not None:
-                a, v = pi.act_step(state, rec)
-            else:
-                a, v, c, h = pi.act(state, c, h)
+            a, v, c, h = pi.act(state, c, h)
             actions[:, t], values[:, t] = a, v
             lengths += active.to(torch.int32)
             xy = torch.stack([a // P, a % P], dim=1)
             state, reward, _ = env.step(xy, host_sync=False)
             rewards[:, t] = reward
         return dict(si=obs, a=actions, values=values, rewards=rewards, lengths=lengths, terminal=env.done.clone())
+
+    def _pull_batch_stepper(self, state):
+        """The acting loop with the recurrent state on the device between steps (``WideStepper``) and nothing in it
+        that needs the host: eager the first time, a graph replay from then on (``rollout_graph``).  The buffers it
+        returns are reused by the next rollout."""
+        env, pi = self.env, self.local_network
+        N, T, P = env.num_envs, self.TIMESTEP_LIMIT, env.size
+        dev = env.device
+        r = self._rollout
+        tensors = (env._state, env.vertices, env.num_vertices, env.predicted_vertices, env.num_predicted,
+                   env.history_points, env.done)
+        where = tuple(t.data_ptr() for t in tensors) + (N, T, P)
+        if r is None or r["where"] != where:
+            r = self._rollout = dict(
+                where=where, graph=None, rec=pi.stepper(N), offset=torch.zeros([], dtype=torch.int64, device=dev),
+                obs=torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev),
+                xy=torch.zeros([N, T, 2], dtype=torch.int32, device=dev),
+                actions=torch.zeros([N, T], dtype=torch.int64, device=dev),
+                values=torch.zeros([N, T], dtype=torch.float32, device=dev),
+                rewards=torch.zeros([N, T], dtype=torch.float64, device=dev),
+                lengths=torch.zeros([N], dtype=torch.int32, device=dev))
+
+        def body():
+            r["rec"].reset()
+            r["lengths"].zero_()
+            state = env._state
+            for t in range(T):
+                active = ~env.done
+                r["obs"][:, t] = state
+                xy, v = pi.act_step_xy(state, r["rec"], r["offset"], P)
+                r["xy"][:, t], r["values"][:, t] = xy, v
+                r["lengths"] += active.to(torch.int32)
+                state, reward, _ = env.step(xy, host_sync=False)
+                r["rewards"][:, t] = reward
+            torch.add(r["xy"][..., 0] * P, r["xy"][..., 1], out=r["actions"])  # x-major class index, as ``act``
+
+        derived = self.derived if isinstance(self.derived, ops.DerivedWeights) else None
+        g = r["graph"]
+        if g is not None and derived is not None and g["generation"] != derived.generation:
+            g = r["graph"] = None  # (a compile moved the weight images the graph reads)
+        if g is not None:
+            if derived is not None:
+                derived.ensure_fresh()
+            g["graph"].replay()
+        elif self.rollout_graph and r.get("warm"):
+            # (the first rollout ran eagerly: library handles, workspaces and the recorded weight images exist)
+            generation = None
+            if derived is not None:
+                derived.compile()
+                generation = derived.generation
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                    body()
+                r["graph"] = dict(graph=graph, generation=generation)
+                graph.replay()  # (a capture records, it does not run)
+            except RuntimeError as err:
+                import warnings
+                warnings.warn("acting loop not captured as a graph (%s): launching it step by step" % err)
+                self.rollout_graph = False
+                body()
+        else:
+            body()
+            r["warm"] = True
+        return dict(si=r["obs"], a=r["actions"], values=r["values"], rewards=r["rewards"], lengths=r["lengths"],
+                    terminal=env.done.clone())
 
     def process(self, images=None, polygons=None):
         with self.derived:

@@ -84,7 +84,7 @@ class BatchedPolygonEnv:
             if vt.shape[1] < need:
                 vt = torch.nn.functional.pad(vt, (0, 0, 0, need - vt.shape[1]))
             self.vcap = int(vt.shape[1])
-            self.vertices, self.num_vertices = vt.contiguous(), nvt.contiguous()
+            self.vertices, self.num_vertices = self._keep("vertices", vt.contiguous()), self._keep("num_vertices", nvt.contiguous())
             img = img.to(self.state_dtype)
         else:
             if images is None:
@@ -93,22 +93,34 @@ class BatchedPolygonEnv:
             vmax_true = max(max(len(p) for p in polygons), util.VMAX_DEFAULT)
             self.vcap = max(vmax_true, hist + self.max_steps + 1)
             vt, nvt = util.pack_polygons(polygons, vmax=self.vcap)
-            self.vertices = torch.from_numpy(vt).to(dev)
-            self.num_vertices = torch.from_numpy(nvt).to(dev)
+            self.vertices = self._keep("vertices", torch.from_numpy(vt).to(dev))
+            self.num_vertices = self._keep("num_vertices", torch.from_numpy(nvt).to(dev))
             img = torch.as_tensor(np.asarray(images), device=dev).to(self.state_dtype)
         size = self.size
-        self.predicted_vertices = torch.zeros([n, self.vcap, 2], dtype=torch.int32, device=dev)
+        # (every tensor of the episode keeps its address from reset to reset while the shapes stay the same: a
+        # rollout captured as a graph reads and writes them in place)
+        self.predicted_vertices = self._keep("predicted_vertices", None, [n, self.vcap, 2], torch.int32).zero_()
         self.predicted_vertices[:, :hist] = self.vertices[:, :hist]
-        self.num_predicted = torch.full([n], hist, dtype=torch.int32, device=dev)
-        self.history_points = self.vertices[:, :hist].clone().contiguous()
-        self.done = torch.zeros([n], dtype=torch.bool, device=dev)
+        self.num_predicted = self._keep("num_predicted", None, [n], torch.int32).fill_(hist)
+        self.history_points = self._keep("history_points", self.vertices[:, :hist].contiguous())
+        self.done = self._keep("done", None, [n], torch.bool).zero_()
         self.steps_taken = 0
-        self._state = torch.empty([n, size, size, 3 + hist], dtype=self.state_dtype, device=dev)
+        self._state = self._keep("_state", None, [n, size, size, 3 + hist], self.state_dtype)
         self._state[..., :3] = img
         if hist:
             self._state[..., 3:] = 0
         self._render_history()
         return self._state
+
+    def _keep(self, name, value, shape=None, dtype=None):
+        """The tensor this environment already holds under ``name`` when it has the wanted shape and type (filled
+        with ``value`` when one is given), else a new one."""
+        old = getattr(self, name, None)
+        if value is not None:
+            shape, dtype = value.shape, value.dtype
+        if old is not None and tuple(old.shape) == tuple(shape) and old.dtype == dtype and old.device == self.device:
+            return old.copy_(value) if value is not None else old
+        return value.clone() if value is not None else torch.empty(list(shape), dtype=dtype, device=self.device)
 
     @property
     def image(self):

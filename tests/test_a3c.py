@@ -155,3 +155,40 @@ def test_stepper_acting_equals_stateless_acting(dtype):
         assert torch.equal(v_a, v_b)
     st = rec.state
     assert torch.equal(st.c, c.to(st.c.dtype)) and torch.equal(st.h, h.to(st.h.dtype))
+
+
+@pytest.mark.gpu
+def test_rollout_replayed_as_a_graph_equals_the_rollout_launched_step_by_step(monkeypatch):
+    """A3C.rollout_graph: the acting loop of the 32-filter policy (encoder, cell, heads, sampling with a device-side
+    stream position, environment step, terminal IoU, T times) captured as a HIP graph against the same loop launched
+    kernel by kernel: observations, actions, values, rewards and lengths of every rollout agree bit for bit over
+    several updates (the weights change in between: the graph reads the refreshed weight images), and so do the
+    parameters after them."""
+    import numpy as np
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl import a3c
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    dev = torch.device("cuda:0")
+    n = 32
+    ds = data.PolygonDataset.synthetic(16, image_size=32, prediction_size=32, max_timesteps=10, history_length=2, seed=30)
+    rs = np.random.RandomState(40)
+    idx = rs.randint(0, len(ds), [n])
+    images = ds._images[idx]
+    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
+    runs = {}
+    for graph in (False, True):
+        env = BatchedPolygonEnv(ds, n, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=dev)
+        trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0, learning_rate=1e-3)
+        trainer.rollout_graph = graph
+        seen = []
+        for _ in range(4):
+            b = trainer.process(images, polygons)
+            seen.append({k: b[k].clone() for k in ("si", "a", "values", "rewards", "lengths")})
+        assert (trainer._rollout["graph"] is not None) == graph
+        runs[graph] = (seen, trainer.opt.flat_param.clone())
+    for a, b in zip(runs[False][0], runs[True][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(runs[False][1], runs[True][1])
+    # successive rollouts draw different actions (the stream position lives on the device and moves with each step)
+    assert not torch.equal(runs[True][0][2]["a"], runs[True][0][3]["a"])
