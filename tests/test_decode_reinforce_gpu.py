@@ -309,3 +309,50 @@ def test_scalar_reinforce_loop_schedule():
         assert np.allclose(c["td"], discount_rewards([0.0] * (c["n"] - 1) + [rewards[k]]))
     applied = sum(1 for k in earning if k in (5, 10))
     assert pol.global_step == applied
+
+
+@pytest.mark.parametrize("B,T,P,end_token", [(3, 5, 28, False), (8, 10, 28, True), (1, 1, 8, False), (64, 5, 28, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sequence_loss_in_two_launches_against_the_oracle(B, T, P, end_token, dtype):
+    """isg_sequence_xent_fwd (labels from (x, y) targets) + isg_sequence_summary (mean loss, the masked metrics and
+    their quotients finished on the device) + isg_softmax_xent_mean_bwd (the mean's backward in one launch, upstream
+    gradient read on the device): loss, gradient and metrics against the oracle's restatement of reference
+    polyrnn/Model.py:39,44-54,98-100, and against the separate entry points they replace."""
+    from imagesegmentation_amd.polyrnn import decode
+    rs = np.random.RandomState(B * 100 + T)
+    K = P * P + (1 if end_token else 0)
+    z = rs.randn(B, T, K) * 2
+    targets = rs.randint(0, P, [B, T, 2])
+    if end_token:
+        targets[0, T - 1] = (P, 0)  # the end token's class is P * P
+    durations = rs.randint(0, T + 1, [B])
+    durations[0] = T
+    tz = torch.tensor(z, dtype=dtype, device=DEV).requires_grad_(True)
+    zr = tz.detach().double().cpu().numpy()
+    tt, td = torch.tensor(targets, dtype=torch.int32, device=DEV), torch.tensor(durations, dtype=torch.int32, device=DEV)
+    loss, m = decode.sequence_loss(tz, tt, td, P)
+    up = torch.tensor(0.5, device=DEV)  # an upstream gradient that is not one
+    loss.backward(gradient=up)
+    labels = targets[..., 0] * P + targets[..., 1]
+    ref_rows = oc.softmax_xent(zr.reshape(B * T, K), labels.reshape(-1))
+    assert abs(loss.item() - ref_rows.mean()) <= 2e-5 * max(1.0, abs(ref_rows.mean()))
+    ref_grad = oc.softmax_xent_backward(zr.reshape(B * T, K), labels.reshape(-1), np.full([B * T], 0.5 / (B * T)))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2 * np.abs(ref_grad).max()
+    assert np.abs(tz.grad.double().cpu().numpy().reshape(B * T, K) - ref_grad).max() <= max(tol, 1e-7)
+    # metrics: the four sums equal isg_sequence_metrics on the kernel's own argmax, the quotients are theirs
+    pred = decode.argmax_rows(tz.detach()).reshape(-1).to(torch.int32)
+    m4 = decode.sequence_metrics(pred, tt, td, P).cpu().numpy()
+    m6 = m.cpu().numpy()
+    assert np.array_equal(m6[:4], m4)
+    n = max(m4[3], 1e-300)
+    if m4[3] > 0:
+        assert m6[4] == m4[0] / n and m6[5] == m4[1] / n
+    if m4[3] > 0:
+        ref = oc.metrics(zr, targets, durations, P)
+        assert abs(m6[4] - ref[0]) <= 1e-12 and abs(m6[5] - ref[1]) <= 1e-9 and abs(m6[2] - ref[2]) <= 1e-9
+    # the separate entry points give the same mean and the same gradient
+    tz2 = tz.detach().clone().requires_grad_(True)
+    loss2 = decode.softmax_xent_mean(tz2, torch.tensor(labels, device=DEV))
+    loss2.backward(gradient=up)
+    assert abs(loss2.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+    assert torch.allclose(tz2.grad.float(), tz.grad.float(), rtol=0, atol=max(tol, 1e-7))

@@ -767,3 +767,68 @@ def test_refresh_after_a_checkpoint_restore_and_in_place_edits():
     with torch.no_grad():
         model.rnn.cells[0].input_to_state_kernel.mul_(0.0)  # (a tracked in-place edit, no epoch change)
     assert valid_loss(model) != base
+
+
+@pytest.mark.gpu
+def test_refresh_entry_point_gathers_and_converts():
+    """isg_refresh_derived through the binding: gathered bf16 and float sections (negative map entries give zero,
+    sections of odd lengths), up to four converted ranges of lengths that are no multiple of 8 and start on odd
+    offsets, against torch indexing; bad arguments are refused."""
+    import ctypes
+    from imagesegmentation_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    n = 100_003
+    src = torch.randn([n], device=dev, generator=g)
+    m16 = torch.randint(-1, n, [5001], device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    m32 = torch.randint(-1, n, [777], device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    o16 = torch.full([5001], 7.0, dtype=torch.bfloat16, device=dev)
+    o32 = torch.full([777], 7.0, dtype=torch.float32, device=dev)
+    ranges = [(1, 4097), (5000, 8), (20001, 30000), (99000, 1003)]
+    outs = [torch.full([k], 7.0, dtype=torch.bfloat16, device=dev) for _, k in ranges]
+    lib = _lib.lib()
+
+    def call(nr, n_src=n):
+        a = (ctypes.c_longlong * 4)(*[r[0] for r in ranges])
+        b = (ctypes.c_longlong * 4)(*[r[1] for r in ranges])
+        c = (ctypes.c_void_p * 4)(*[o.data_ptr() for o in outs])
+        return lib.isg_refresh_derived(_lib.ptr(src), n_src, _lib.ptr(m16), m16.numel(), _lib.ptr(o16), _lib.ptr(m32),
+                                       m32.numel(), _lib.ptr(o32), nr, a, b, c, _lib.current_stream())
+    assert call(4) == 0
+    gather = lambda m: torch.where(m >= 0, src[m.clamp(min=0).long()], torch.zeros([], device=dev))
+    assert torch.equal(o16, gather(m16).to(torch.bfloat16)) and torch.equal(o32, gather(m32))
+    for (a, k), o in zip(ranges, outs):
+        assert torch.equal(o, src[a:a + k].to(torch.bfloat16))
+    assert call(5) != 0                    # more than four ranges
+    assert call(4, n_src=99_000) != 0      # a range that ends past the source
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("KS,C,cin", [(3, 32, 5), (5, 32, 3), (3, 16, 5)])
+def test_padded_input_layer_on_the_square_kernels(KS, C, cin):
+    """A layer with fewer input channels than filters on isg_conv32 / isg_conv16 over a zero-padded input
+    (isg_conv32_pack_padded) against a float64 convolution of the bf16-rounded operands, forward and weight / bias
+    gradients (reference polyrl/a3c/model.py:19-20: 5 -> 32 channels, 3 x 3)."""
+    from imagesegmentation_amd.polyrnn.Model import conv2d_same_relu
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(KS * 100 + C + cin)
+    x = torch.randn([3, 21, 37, cin], device=dev, generator=g).bfloat16()
+    w = (torch.randn([KS, KS, cin, C], device=dev, generator=g) * 0.2).requires_grad_(True)
+    b = (torch.randn([C], device=dev, generator=g) * 0.1).requires_grad_(True)
+    y = conv2d_same_relu(x, w, b, torch.bfloat16)
+    up = torch.randn(y.shape, device=dev, generator=g).bfloat16()
+    y.backward(up)
+    xd = x.double().permute(0, 3, 1, 2)
+    wd = w.detach().bfloat16().double().permute(3, 2, 0, 1).requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.conv2d(xd, wd, bd, padding=KS // 2)).permute(0, 2, 3, 1)
+    assert (y.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # the backward pass sees the bf16 output's mask and the bf16 upstream gradient
+    (ref * 0).sum().backward()
+    wd.grad = None
+    bd.grad = None
+    pre = torch.nn.functional.conv2d(xd, wd, bd, padding=KS // 2)
+    (torch.relu(pre).permute(0, 2, 3, 1) * up.double()).sum().backward()
+    gw = wd.grad.permute(2, 3, 1, 0)
+    assert (w.grad.double() - gw).abs().max().item() <= 3e-2 * gw.abs().max().item()
+    assert (b.grad.double() - bd.grad).abs().max().item() <= 3e-2 * bd.grad.abs().max().item()
