@@ -586,6 +586,31 @@ class GpuWorkload:
                     "in_step_ms_by_label": {k: round(v, 4) for k, v in sorted(in_step.items())}}
         return kernels, roofline
 
+    def encoder_rooflines(self, in_step):
+        """The encoder's launches as timed inside the step (ops.timeline labels), each against both roofs: algorithmic
+        bytes = every operand read once and every result written once, FLOPs = 2 x taps x Cin x Cout per pixel."""
+        px = float(self.share["batch"]) * self.size * self.size
+        peak = MFMA_PEAK_TFLOPS["bf16" if self.dtype == torch.bfloat16 else "f32"]
+        out = []
+        for label, ms in sorted(in_step.items()):
+            name, _, shape = label.partition("[")
+            if name not in ("conv_in_fwd", "conv_in_wgrad", "conv32", "conv32_masked", "conv32_wgrad", "relu_bwd_bias"):
+                continue
+            nums = [int(v) for v in shape.replace("]", "").replace("C=", "").replace("x", " ").split()]
+            if name.startswith("conv_in"):
+                ks, c = nums[0], self.model.encoder[0][0].shape[3]
+                flops, nbytes = 2.0 * ks * ks * 3 * c * px, (8 + 2 * c) * px  # the image padded to 4 channels in
+            elif name == "relu_bwd_bias":
+                c = nums[0]
+                flops, nbytes = 0.0, 3 * 2 * c * px
+            else:
+                ks, c = nums[0], nums[2]
+                flops = 2.0 * ks * ks * c * c * px
+                nbytes = (3 if name == "conv32_masked" else 2) * 2 * c * px
+            out.append({"kernel": label, "ms": ms, "flops": flops, "bytes": nbytes,
+                        "mfma_frac": flops / (ms * 1e-3) / (peak * 1e12), "hbm_frac": nbytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)})
+        return out
+
     def cpu_baseline(self):
         return cpu_baseline_convlstm(self.model, self.batch, self.size, self.T, self.hist, self.head_size)
 
@@ -766,6 +791,9 @@ class StubWorkload:
     def kernel_rooflines(self, in_step):
         return None, None
 
+    def encoder_rooflines(self, in_step):
+        return []
+
     def cpu_baseline(self):
         return None
 
@@ -870,6 +898,8 @@ def run_legs(args, world, rank, w):
             w.train_step()  # fault injection for the launch check's own test: a step only rank 0 takes
         if rank == 0:
             kernels, roofline = w.kernel_rooflines(in_step)  # isolated launches, no collective
+            if kernels is not None:
+                kernels = kernels + w.encoder_rooflines(in_step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("CPU baseline of the training step (bounded sample)")
         cpu = w.cpu_baseline()

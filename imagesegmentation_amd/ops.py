@@ -340,6 +340,25 @@ def _timed(name):
     return deco
 
 
+def _timed_as(label_of):
+    """As ``_timed`` with the label made from the call's arguments (the encoder's launches are told apart by their
+    shapes, not by a recurrence layer)."""
+    def deco(fn):
+        def wrapper(*args, **kwargs):
+            tl = _timeline
+            if tl is None:
+                return fn(*args, **kwargs)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(*args, **kwargs)
+            b.record()
+            tl.records.append((label_of(*args, **kwargs), a, b))
+            return out
+        wrapper.__doc__, wrapper.__name__ = fn.__doc__, fn.__name__
+        return wrapper
+    return deco
+
+
 def _need_cuda(t, name):
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU: libisg has no CPU path" % name)
@@ -655,6 +674,7 @@ def bias_relu_(y, bias):
 _bias_ws = {}
 
 
+@_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])
 def relu_bwd_bias(dy, y, dbias_out=None):
     """(dz, dbias): dz = dy masked by y > 0 (written over dy when dy is contiguous and owns its memory),
     dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given)."""
@@ -715,6 +735,7 @@ def conv_in_pad_image(x3):
     return x4
 
 
+@_timed_as(lambda x4, wimg, bias, ks, relu=True: "conv_in_fwd[%dx%d]" % (ks, ks))
 def conv_in_fwd(x4, wimg, bias, ks, relu=True):
     B, H, W, _ = x4.shape
     cout = bias.shape[0]
@@ -728,6 +749,7 @@ def conv_in_fwd(x4, wimg, bias, ks, relu=True):
 _conv_in_ws = {}
 
 
+@_timed_as(lambda x4, dz, ks, out=None: "conv_in_wgrad[%dx%d]" % (ks, ks))
 def conv_in_wgrad(x4, dz, ks, out=None):
     """float32 [KS,KS,3,cout] weight gradient from the padded image and the masked output gradient."""
     B, H, W, _ = x4.shape
@@ -809,6 +831,7 @@ def conv32_padded_supported(w_hwio, dtype, device):
             _lib.lib().isg_conv32_packed_elems(int(kh)) > 0)
 
 
+@_timed_as(lambda x, wimg, bias, ks, relu: "conv32[%dx%d C=%d]" % (ks, ks, x.shape[-1]))
 def conv32(x, wimg, bias, ks, relu):
     B, H, W, c = x.shape
     assert c in (16, 32) and x.dtype == torch.bfloat16 and x.is_contiguous()
@@ -823,6 +846,7 @@ def conv32(x, wimg, bias, ks, relu):
 _conv32_mask_ws = {}
 
 
+@_timed_as(lambda dz, wimg_dgrad, y_below, ks, dbias_out=None: "conv32_masked[%dx%d C=%d]" % (ks, ks, dz.shape[-1]))
 def conv32_masked(dz, wimg_dgrad, y_below, ks, dbias_out=None):
     """(dz_below, dbias_below): the data gradient of a conv32 / conv16 layer masked by the ReLU of the layer below
     (``y_below`` = that layer's output) and the masked values summed per channel (float32 [C]) - the layer below's
@@ -848,6 +872,7 @@ def conv32_masked(dz, wimg_dgrad, y_below, ks, dbias_out=None):
 _conv32_ws = {}
 
 
+@_timed_as(lambda x, dz, ks, out=None: "conv32_wgrad[%dx%d C=%d]" % (ks, ks, x.shape[-1]))
 def conv32_wgrad(x, dz, ks, out=None):
     B, H, W, c = x.shape
     assert x.is_contiguous() and dz.is_contiguous() and dz.dtype == torch.bfloat16 and dz.shape == x.shape and c in (16, 32)
