@@ -28,13 +28,29 @@ if forced:
     dist.init_process_group("nccl", rank=0, world_size=1)
 ds = data.PolygonDataset.synthetic(16, 28, 28, 10, 2, seed=1)
 model = experiments.make("History2Large", image_size=28, compute_dtype=torch.bfloat16, device="cuda:0", seed=3)
+model.step_graphs = os.environ.get("ISG_TEST_STEP_GRAPHS") == "1"
 np.random.seed(0)
 d, images, pts, t, _ = ds.get_batch_points(8)
 losses = [model.train_step(images, d, pts, t).item() for _ in range(3)]
 torch.cuda.synchronize()
 flat = torch.cat([p.detach().float().reshape(-1) for p in model.trainable_variables])
 out = dict(losses=losses, checksum=float(flat.double().sum()), absum=float(flat.double().abs().sum()),
-           early=int(model._early_reduce.early_launches), on=bool(parallel._collectives_on()))
+           early=int(model._early_reduce.early_launches), on=bool(parallel._collectives_on()),
+           graphs=len(model._step_graph_cache))
+# the actor-critic trainer: acting loop replayed as a graph, one-piece all-reduce inside FlatAdam.step
+from imagesegmentation_amd.polyrl import a3c
+from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+ds32 = data.PolygonDataset.synthetic(16, image_size=32, prediction_size=32, max_timesteps=10, history_length=2, seed=30)
+rs = np.random.RandomState(40)
+idx = rs.randint(0, len(ds32), [16])
+polys = [np.roll(ds32._vertices[i], rs.randint(len(ds32._vertices[i])), axis=0) for i in idx]
+env = BatchedPolygonEnv(ds32, 16, end_token=False, max_steps=10, device=torch.device("cuda:0"))
+trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0)
+for _ in range(3):
+    trainer.process(ds32._images[idx], polys)
+torch.cuda.synchronize()
+out["a3c"] = float(trainer.opt.flat_param.double().sum())
+out["a3c_graph"] = trainer._rollout["graph"] is not None
 if forced:
     # the REINFORCE / actor-critic optimiser's one-piece all-reduce, and the timing reduction of bench.py
     g = torch.arange(1000, dtype=torch.float32, device="cuda:0")
@@ -46,11 +62,14 @@ print("RESULT " + json.dumps(out))
 """ % ROOT
 
 
-def _run(forced):
+def _run(forced, step_graphs=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ISG_FORCE_COLLECTIVES", None)
+    env.pop("ISG_TEST_STEP_GRAPHS", None)
     if forced:
         env["ISG_FORCE_COLLECTIVES"] = "1"
+    if step_graphs:
+        env["ISG_TEST_STEP_GRAPHS"] = "1"
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -65,3 +84,8 @@ def test_one_rank_rccl_group_runs_every_collective_and_changes_nothing():
     assert forced["losses"] == plain["losses"]
     assert forced["checksum"] == plain["checksum"] and forced["absum"] == plain["absum"]
     assert forced["one_piece"] == float(sum(range(1000))) and forced["max"] == 1.5
+    assert forced["a3c"] == plain["a3c"] and forced["a3c_graph"] and plain["a3c_graph"]
+    # the training step replayed as a graph: the exchange (one piece, after the replay), clip and Adam stay outside
+    graphed = _run(True, step_graphs=True)
+    assert graphed["graphs"] >= 1 and graphed["early"] == 0
+    assert graphed["losses"] == plain["losses"] and graphed["checksum"] == plain["checksum"]
