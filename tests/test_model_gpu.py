@@ -694,8 +694,9 @@ def test_graph_replayed_training_step_equals_the_eager_step(name, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["RNNConv", "EndTokenDeep_2", "History2Large"])
-def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(name, monkeypatch):
+@pytest.mark.parametrize("name,dtype", [("RNNConv", torch.bfloat16), ("EndTokenDeep_2", torch.bfloat16),
+                                        ("History2Large", torch.bfloat16), ("History2Large", torch.float32)])
+def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(name, dtype, monkeypatch):
     """ops.DerivedWeights: after the first training step every weight image, tap table and compute-type copy the
     step used is a view of two shared buffers that ONE launch (isg_refresh_derived) fills from the flat parameter
     buffer through index maps - derived by running the packing kernels on index values.  Checked: (1) after
@@ -709,7 +710,7 @@ def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(na
     for off in (False, True):
         if off:
             monkeypatch.setenv("ISG_NO_DERIVED", "1")
-        model = experiments.make(name, image_size=28, compute_dtype=torch.bfloat16, device="cuda:0", seed=5,
+        model = experiments.make(name, image_size=28, compute_dtype=dtype, device="cuda:0", seed=5,
                                  learning_rate=1e-3)
         np.random.seed(77)
         losses = []
@@ -721,7 +722,10 @@ def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(na
             reg = model._derived
             assert isinstance(reg, ops.DerivedWeights) and reg._plan is not None and not reg._recorded
             # one LSTM entry per layer, the head, the first encoder layer, two images per further encoder layer
-            assert len(reg._compiled) == len(model.rnn.cells) + 1 + 1 + 2 * (len(model.encoder) - 1)
+            # (a float model: the cells' float images only - its encoder runs on the vendor convolution and its
+            # head reads the master weights)
+            assert len(reg._compiled) == len(model.rnn.cells) + \
+                (1 + 1 + 2 * (len(model.encoder) - 1) if dtype == torch.bfloat16 else 0)
             reg.ensure_fresh()
             for key, (obj, names, recompute, _) in reg._compiled.items():
                 before = {n: getattr(obj, n).clone() for n in names if getattr(obj, n) is not None}
@@ -732,7 +736,11 @@ def test_one_refresh_launch_gives_every_packed_image_the_packing_kernels_give(na
                     got = getattr(obj, n)
                     assert torch.equal(got.view(torch.int16) if got.dtype == torch.bfloat16 else got,
                                        ref.view(torch.int16) if ref.dtype == torch.bfloat16 else ref), (key, n)
-    assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1], runs[True][1])
+    if dtype == torch.bfloat16:
+        assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1], runs[True][1])
+    else:  # (the vendor convolution's weight gradient is not bit-reproducible between two runs)
+        assert torch.allclose(runs[False][0], runs[True][0], rtol=1e-4) and \
+            torch.allclose(runs[False][1], runs[True][1], atol=1e-4)
     assert bool((runs[False][0][-1] < runs[False][0][0]).item())
 
 
