@@ -47,10 +47,19 @@ int num_cus() {
 // ---------------------------------------------------------------------------------------------
 // forward / data gradient
 // ---------------------------------------------------------------------------------------------
+#ifndef ISG_C32_NPT5
+#define ISG_C32_NPT5 4
+#endif
+// tile rows per wave: the more rows, the fewer LDS reads per MFMA (see the k-loop); the 5 x 5, 32-channel kernel holds
+// one workgroup per CU whatever its tile (50 KB of weights), so it takes the largest tile that fits beside them
+template <int KS, int CH>
+constexpr int rows_per_wave() { return KS == 5 && CH == 32 ? ISG_C32_NPT5 : 2; }
+
 template <int KS, int CH>
 struct CF {
     static_assert(CH == 16 || CH == 32, "channels in = channels out = 16 or 32");
-    static constexpr int TH = 16;                     // tile rows: 2 per wave
+    static constexpr int NPT = rows_per_wave<KS, CH>();
+    static constexpr int TH = (kThreads / 64) * NPT;  // tile rows
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int SPT = CH / 16;               // k-steps per tap: 16-channel groups
     static constexpr int NCHK = CH / 8;               // 16-byte chunks per pixel
@@ -149,56 +158,66 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         const bool valid = tile_origin(k, b, ty0, tx0);
         stage_load(k + 1);
         if (valid) {
-            uint2 mk[2][2 * K::SPT];  // MASK: the mask values of this lane's rows, requested ahead of the k-loop
+            constexpr int NPT = K::NPT;
+            uint2 mk[NPT][2 * K::SPT];  // MASK: the mask values of this lane's rows, requested ahead of the k-loop
             if constexpr (MASK) {
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const int cy = min(ty0 + 2 * wave + pt, p.H - 1), cx = min(tx0 + px_l, p.W - 1);
+                for (int pt = 0; pt < NPT; ++pt) {
+                    const int cy = min(ty0 + NPT * wave + pt, p.H - 1), cx = min(tx0 + px_l, p.W - 1);
                     const char* src = static_cast<const char*>(p.mask) + (((size_t)b * p.H + cy) * p.W + cx) * (CH * 2);
 #pragma unroll
                     for (int g = 0; g < 2 * K::SPT; ++g) mk[pt][g] = *reinterpret_cast<const uint2*>(src + (8 * g + 4 * half) * 2);
                 }
             }
-            f32x16 acc[2];
+            f32x16 acc[NPT];
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
-            const char* bb = lds_in + ((2 * wave) * K::HWP + px_l) * K::PSTRIDE + half * 16;
+            const char* bb = lds_in + ((NPT * wave) * K::HWP + px_l) * K::PSTRIDE + half * 16;
             const char* aw = lds_w + lane * 16;
-            // Two MFMAs (64 cycles) per k-step against an LDS round trip of 64 - 130: the fragments are requested
-            // AHEAD k-steps before their MFMAs.
+            // The k-loop goes column by column: a column = one tap column tx and one 16-channel group q.  Its KS taps
+            // (ty) on the wave's NPT pixel rows read NPT + KS - 1 rows of the tile, each fetched ONCE and used by
+            // every (ty, pt) pair with ty + pt = row: NPT + 2 KS - 1 LDS reads of 1 KB per NPT KS MFMAs in place of
+            // the KS (NPT + 1) of a loop that fetches per tap (5 x 5: 1.1 KB per MFMA at 2 rows, 0.65 at 4, from 1.5;
+            // four SIMDs' MFMAs take 1 KB per 8 LDS cycles... the LDS delivers 128 B a cycle, so 1 KB per MFMA is
+            // where the matrix cores and the LDS are level).
+            // A sub-step = one tap of a column (NPT MFMAs); its fragments are requested AHEAD sub-steps before.
 #ifndef ISG_C32_AHEAD
 #define ISG_C32_AHEAD 2
 #endif
-            constexpr int AHEAD = ISG_C32_AHEAD, NB = AHEAD + 1;
-            bf16x8 af[NB], bf[NB][2];
-            auto fetch = [&](int s, int slot) {
-                const int tap = s / K::SPT, q = s % K::SPT;
-                const int ty = tap / KS, tx = tap - ty * KS;
-                af[slot] = *reinterpret_cast<const bf16x8*>(aw + s * 1024);
+            constexpr int AHEAD = NPT >= 4 ? 1 : ISG_C32_AHEAD, NB = AHEAD + 1;
+            constexpr int NR = NPT + KS - 1, NU = KS * K::SPT * KS;
+            static_assert(AHEAD < KS, "two column buffers");
+            bf16x8 af[NB], rows[2][NR];
+            auto fetch = [&](int u) {
+                const int col = u / KS, ty = u - col * KS;
+                const int tx = col / K::SPT, q = col - tx * K::SPT;
+                af[u % NB] = *reinterpret_cast<const bf16x8*>(aw + ((ty * KS + tx) * K::SPT + q) * 1024);
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-                    bf[slot][pt] = *reinterpret_cast<const bf16x8*>(bb + ((ty + pt) * K::HWP + tx) * K::PSTRIDE + q * 32);
+                for (int r = 0; r < NR; ++r)
+                    if (r == ty + NPT - 1 || (ty == 0 && r < NPT - 1))
+                        rows[col & 1][r] = *reinterpret_cast<const bf16x8*>(bb + (r * K::HWP + tx) * K::PSTRIDE + q * 32);
             };
 #ifndef ISG_C32_NO_KLOOP  // (diagnostic builds leave a part out to see what the others take)
 #pragma unroll
-            for (int s = 0; s < AHEAD; ++s) fetch(s, s);
+            for (int u = 0; u < AHEAD; ++u) fetch(u);
 #pragma unroll
-            for (int s = 0; s < K::NS; ++s) {
-                if (s + AHEAD < K::NS) fetch(s + AHEAD, (s + AHEAD) % NB);
+            for (int u = 0; u < NU; ++u) {
+                if (u + AHEAD < NU) fetch(u + AHEAD);
+                const int col = u / KS, ty = u - col * KS;
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
-                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % NB], bf[s % NB][pt], acc[pt], 0, 0, 0);
+                for (int pt = 0; pt < NPT; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u % NB], rows[col & 1][ty + pt], acc[pt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
             // epilogue: lane = pixel; its 16 accumulators are rows 8g + 4 half + i (g = reg >> 2, i = reg & 3).
             // The two halves swap two row groups so that each lane stores whole 16-byte runs of 8 channels.
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
+            for (int pt = 0; pt < NPT; ++pt) {
                 unsigned pk[4][2];
-                const bool px_in = ty0 + 2 * wave + pt < p.H && tx0 + px_l < p.W;
+                const bool px_in = ty0 + NPT * wave + pt < p.H && tx0 + px_l < p.W;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                         const unsigned send = half ? pk[2 * c][w] : pk[2 * c + 1][w];
                         recv[c][w] = __shfl_xor(send, 32);
                     }
-                const int gy = ty0 + 2 * wave + pt, gx = tx0 + px_l;
+                const int gy = ty0 + NPT * wave + pt, gx = tx0 + px_l;
                 unsigned out[K::SPT][4];
 #pragma unroll
                 for (int c = 0; c < K::SPT; ++c) {
@@ -239,7 +258,11 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                     out[c][2] = half ? k0 : recv[c][0], out[c][3] = half ? k1 : recv[c][1];
                 }
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef ISG_C32_NO_STORE  // (diagnostic build: the epilogue without its stores)
+                if (gy < p.H && gx < p.W && p.relu == 12345) {
+#else
                 if (gy < p.H && gx < p.W) {
+#endif
                     char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2);
 #pragma unroll
                     for (int c = 0; c < K::SPT; ++c)
