@@ -459,9 +459,11 @@ class RecurrentStepper:
 
 class WideStepper:
     """One cell of 16 k filters advanced one step at a time, without autograd (acting in a rollout): the state stays
-    split by 16-filter group in ping-pong buffers and the joint input [x | h[16:]] in one buffer across steps, so a
-    step is one copy of x, one of each further group's h, k fused cell launches and the join of the k outputs -
-    where a ``dynamic_rnn`` call per step would split and rejoin the whole state every time."""
+    split by 16-filter group and nothing is joined by a copy - the joint input [x | h[16:]] lives in two buffers that
+    alternate from step to step, every further group writes its h straight into the NEXT step's buffer (the cell
+    kernel's strided h output) and every group writes its 16 channels of the joint output (its strided masked
+    output).  A step is one copy of x and k fused cell launches, where a ``dynamic_rnn`` call per step would split
+    and rejoin the whole state every time."""
 
     def __init__(self, cell, batch, device, initial_state=None):
         self.cell = cell
@@ -471,43 +473,47 @@ class WideStepper:
         self.C = int(cell.input_to_state_kernel.shape[2])
         self.groups = _wide_groups(cell, self.C)
         cs = self.groups[0][1].cs
-        self.xw = torch.zeros([batch, H, W, cs], dtype=dt, device=device)
-        self.H = [torch.zeros([2, batch, H, W, Fh], dtype=dt, device=device) for _ in range(self.k)]
+        self.xw = torch.zeros([2, batch, H, W, cs], dtype=dt, device=device)   # [x | h of groups 1..k-1 | padding]
+        self.H0 = torch.zeros([2, batch, H, W, Fh], dtype=dt, device=device)   # group 0's h: the recurrent input
         self.Cst = [torch.zeros([2, batch, H, W, Fh], dtype=torch.float32, device=device) for _ in range(self.k)]
-        self.outs = [torch.empty([batch, 1, H, W, Fh], dtype=dt, device=device) for _ in range(self.k)]
+        self.out = torch.empty([batch, H, W, F], dtype=dt, device=device)
         self.cur = 0
-        self._stride = H * W * Fh
         if initial_state is not None:
             c0, h0 = initial_state
+            self.H0[0].copy_(h0[..., :Fh])
+            self.xw[0][..., self.C:self.C + F - Fh] = h0[..., Fh:]
             for g in range(self.k):
                 self.Cst[g][0].copy_(c0[..., Fh * g:Fh * g + Fh])
-                self.H[g][0].copy_(h0[..., Fh * g:Fh * g + Fh])
 
     def reset(self):
         """Back to the zero state, in place (the buffers keep their addresses: a captured graph may hold them)."""
-        for t in self.H + self.Cst:
+        for t in [self.xw, self.H0] + self.Cst:
             t.zero_()
         self.cur = 0
 
     @property
     def state(self):
         """(c, h) of the whole cell, joined (a copy)."""
-        cur = self.cur
-        return LSTMStateTuple(torch.cat([c[cur] for c in self.Cst], dim=-1), torch.cat([h[cur] for h in self.H], dim=-1))
+        cur, C, F, Fh = self.cur, self.C, self.cell._filters, ops.F_HIDDEN
+        return LSTMStateTuple(torch.cat([c[cur] for c in self.Cst], dim=-1),
+                              torch.cat([self.H0[cur], self.xw[cur][..., C:C + F - Fh]], dim=-1))
 
     def step(self, x):
-        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step."""
-        Fh, C = ops.F_HIDDEN, self.C
+        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step: a buffer of the stepper that the next
+        step overwrites."""
+        Fh, C, F = ops.F_HIDDEN, self.C, self.cell._filters
         cur, nxt = self.cur, 1 - self.cur
         groups = _wide_groups(self.cell, C)  # (re-packed when the weights have changed)
-        self.xw[..., :C] = x
-        for g in range(1, self.k):
-            self.xw[..., C + Fh * (g - 1):C + Fh * g] = self.H[g][cur]
+        xw, cs = self.xw[cur], self.xw.shape[-1]
+        _, H, W, _ = xw.shape
+        ops.copy_slice(xw[..., :C], x if x.dtype == xw.dtype else x.to(xw.dtype))
         for g in range(self.k):
-            ops.cell_fwd(self.xw, self.H[0][cur], self.Cst[g][cur], groups[g][1], None, 0, out=self.outs[g],
-                         out_batch_stride=self._stride, save_gates=False, h_out=self.H[g][nxt], c_out=self.Cst[g][nxt])
+            h_out = self.H0[nxt] if g == 0 else self.xw[nxt][..., C + Fh * (g - 1):C + Fh * g]
+            ops.cell_fwd(xw, self.H0[cur], self.Cst[g][cur], groups[g][1], None, 0,
+                         out=self.out[..., Fh * g:Fh * g + Fh], out_batch_stride=H * W * F, out_pixel_stride=F,
+                         save_gates=False, h_out=h_out, h_pixel_stride=Fh if g == 0 else cs, c_out=self.Cst[g][nxt])
         self.cur = nxt
-        return torch.cat([o[:, 0] for o in self.outs], dim=-1)
+        return self.out
 
 
 class _SequenceFunction(torch.autograd.Function):
@@ -736,21 +742,21 @@ class _WideSequenceFunction(torch.autograd.Function):
         layout = ops.SAVE_FACTORS if ops.bwd_fused_supported(groups[0][1], B, H, W) else ops.SAVE_GATES
         Gs = [torch.empty([t_run] + ops.saved_shape(B, H, W, Fh, layout), dtype=dt, device=dev) if keep else None
               for _ in range(k)]
-        # every step that runs writes its whole output slice (zeros for finished samples): only steps past the
-        # longest sequence need the fill
-        outs = [torch.empty([B, T, H, W, Fh], dtype=dt, device=dev) for _ in range(k)]
+        # every step that runs writes its whole output slice (zeros for finished samples), each group its 16 channels
+        # of the joint output: only steps past the longest sequence need the fill
+        out = torch.empty([B, T, H, W, F], dtype=dt, device=dev)
         if t_run < T:
-            for o in outs:
-                o[:, t_run:] = 0
+            out[:, t_run:] = 0
         live = None
         for t in range(t_run):
             for s in range(1, k):
-                xw[t, ..., C + Fh * (s - 1):C + Fh * s] = Hs[s][t]
+                ops.copy_slice(xw[t, ..., C + Fh * (s - 1):C + Fh * s], Hs[s][t])
             if durations_dev is not None:
                 live = (durations_dev > t).view(-1, 1, 1, 1)
             for s in range(k):
-                ops.cell_fwd(xw[t], Hs[0][t], Cs[s][t], groups[s][1], durations_dev, t, out=outs[s][:, t],
-                             out_batch_stride=T * H * W * Fh, save_gates=False, h_out=Hs[s][t + 1], c_out=Cs[s][t + 1],
+                ops.cell_fwd(xw[t], Hs[0][t], Cs[s][t], groups[s][1], durations_dev, t,
+                             out=out[:, t, ..., Fh * s:Fh * s + Fh], out_batch_stride=T * H * W * F, out_pixel_stride=F,
+                             save_gates=False, h_out=Hs[s][t + 1], c_out=Cs[s][t + 1],
                              gates=Gs[s][t] if keep else None, save_layout=layout)
                 if s > 0 and live is not None:
                     # a finished sample's state passes through; the kernel copied its RECURRENT input (group 0's h)
@@ -759,7 +765,6 @@ class _WideSequenceFunction(torch.autograd.Function):
         ctx.saved = (xw, Hs, Cs, Gs, groups, layout)
         ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
         ctx.set_materialize_grads(False)
-        out = torch.cat(outs, dim=-1)
         return out, torch.cat([Cs[s][t_run] for s in range(k)], dim=-1), torch.cat([Hs[s][t_run] for s in range(k)], dim=-1)
 
     @staticmethod
@@ -788,10 +793,14 @@ class _WideSequenceFunction(torch.autograd.Function):
             d_out_g = d_out.to(dt).reshape(B, T, H, W, k, Fh).permute(4, 0, 1, 2, 3, 5).contiguous()
         else:
             d_out_g = torch.zeros([k, B, T, H, W, Fh], dtype=dt, device=dev)
-        d_x = torch.zeros([T, B, H, W, C], dtype=dt, device=dev)
+        # the gradient of the joint input [x | h[16:]] of every step, written in place by the data-gradient launches:
+        # its x channels are the node's input gradient (a view, no copy per step)
+        d_xw = torch.empty([T, B, H, W, cs], dtype=dt, device=dev)
+        if t_run < T:
+            d_xw[t_run:] = 0
         dy = torch.empty([B, H, W, Fh, 4], dtype=dt, device=dev)
-        dxw = torch.empty([B, H, W, cs], dtype=dt, device=dev)
-        dh_extra = torch.zeros([B, H, W, Fh], dtype=dt, device=dev)
+        # (one per further group: each holds its group's gradient of the shared recurrent input until the sum below)
+        dh_extras = [None] + [torch.zeros([B, H, W, Fh], dtype=dt, device=dev) for _ in range(1, k)]
         gw = [(torch.zeros([3, 3, C + F - Fh, 4 * Fh], dtype=torch.float32, device=dev),
                torch.zeros([3, 3, Fh, 4 * Fh], dtype=torch.float32, device=dev),
                torch.zeros([4 * Fh], dtype=torch.float32, device=dev)) for _ in range(k)]
@@ -800,7 +809,9 @@ class _WideSequenceFunction(torch.autograd.Function):
             live = (durations_dev > t).view(-1, 1, 1, 1) if durations_dev is not None else None
             mode = ops.WGRAD_DEFER if t < t_run - 1 else ops.WGRAD_DEFER_FIRST
             dh0_sum = None
+            dxw = d_xw[t]
             for s in range(k):
+                dh_extra = dh_extras[s]
                 if fused:
                     # the recurrent input of every group is group 0's h: group 0's gradient of it becomes the carried
                     # one (a finished sample keeps its carried value), the other groups' are added to it below
@@ -811,7 +822,7 @@ class _WideSequenceFunction(torch.autograd.Function):
                     dc_state[s], dc_next[s] = dc_next[s], dc_state[s]
                     if s > 0:
                         # (for a finished sample the kernel passes the group's OWN carried gradient through)
-                        extra = dh_extra.clone() if live is None else torch.where(live, dh_extra, torch.zeros_like(dh_extra))
+                        extra = dh_extra if live is None else torch.where(live, dh_extra, torch.zeros_like(dh_extra))
                         dh0_sum = extra if dh0_sum is None else dh0_sum + extra
                     continue
                 ops.pointwise_bwd(Gs[s][t], Cs[s][t], Cs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s], dc_state[s],
@@ -826,15 +837,17 @@ class _WideSequenceFunction(torch.autograd.Function):
                 ops.dgrad(dy, groups[s][1], dh_state[0] if s == 0 else dh_extra, dx=dxw, dx_channels=cs,
                           dx_accumulate=s > 0, durations=durations_dev, t=t)
                 if s > 0:
-                    dh0_sum = dh_extra.clone() if dh0_sum is None else dh0_sum + dh_extra
+                    dh0_sum = dh_extra if dh0_sum is None else dh0_sum + dh_extra
             if fused:
                 dh_state[0], dh_next0 = dh_next0, dh_state[0]
             if dh0_sum is not None:
                 dh_state[0] += dh0_sum
-            d_x[t] = dxw[..., :C]
             for s in range(1, k):  # h_prev[16 s:] entered through the joint input
                 g = dxw[..., C + Fh * (s - 1):C + Fh * s]
-                dh_state[s] = (torch.where(live, g, dh_state[s]) if live is not None else g).contiguous()
+                if live is not None:
+                    dh_state[s] = torch.where(live, g, dh_state[s]).contiguous()
+                else:
+                    dh_state[s] = ops.copy_slice(torch.empty([B, H, W, Fh], dtype=dt, device=dev), g)
         dw_x = torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32)
         dw_h = torch.zeros_like(cell.hidden_to_state_kernel, dtype=torch.float32)
         dbias = torch.zeros_like(cell.bias, dtype=torch.float32)
@@ -848,7 +861,7 @@ class _WideSequenceFunction(torch.autograd.Function):
             dbias[cols] = gw[s][2]
         xd, cd, hd = ctx.in_dtypes
         ctx.saved = ctx.cell = None
-        return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
+        return (None, None, None, d_xw[..., :C].to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
                 dw_x, dw_h, dbias)
 
 

@@ -721,7 +721,8 @@ int cell_fwd_impl(const void* x, const void* h_prev, const void* c_prev_v, const
                   int B, int H, int W, int Cs, int F, int dtype, const int32_t* durations, int t,
                   const int32_t* hist_points, int hist, long long hist_batch_stride, const float* hist_table,
                   void* h_out, void* c_out_v, void* out, long long out_batch_stride, void* gates, int save_layout,
-                  void* pool_out, long long pool_batch_stride, void* stream) {
+                  void* pool_out, long long pool_batch_stride, void* stream, int h_pixel_stride = F_,
+                  int out_pixel_stride = F_) {
     const bool state_bf16 = (save_layout & ISG_STATE_BF16) != 0;
     save_layout &= ~ISG_STATE_BF16;
     // (typed as float in the kernels' parameter block; the bf16 instantiations cast it back)
@@ -735,6 +736,10 @@ int cell_fwd_impl(const void* x, const void* h_prev, const void* c_prev_v, const
     ISG_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), ISG_EINVAL,
                 "isg_convlstm_cell_fwd: h_prev and c_prev are both given or both NULL (the zero state)");
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "isg_convlstm_cell_fwd: bad shape");
+    ISG_REQUIRE(h_pixel_stride >= F_ && h_pixel_stride % 8 == 0 && out_pixel_stride >= F_ && out_pixel_stride % 8 == 0 &&
+                    (long long)B * H * W < (1LL << 31),
+                ISG_EINVAL, "isg_convlstm_cell_fwd_strided: pixel strides are multiples of 8 elements and at least %d "
+                "(got %d and %d)", F_, h_pixel_stride, out_pixel_stride);
     ISG_REQUIRE(hist >= 0 && (hist == 0 || (hist_points && hist_table)), ISG_EINVAL,
                 "isg_convlstm_cell_fwd: history points and table are needed when hist > 0");
     ISG_REQUIRE(save_layout == ISG_SAVE_GATES || (save_layout == ISG_SAVE_FACTORS && (dtype == ISG_BF16 || !gates)),
@@ -752,6 +757,7 @@ int cell_fwd_impl(const void* x, const void* h_prev, const void* c_prev_v, const
     p.bias = bias, p.c_prev = c_prev, p.c_out = c_out, p.h_out = h_out, p.out = out;
     p.state_bf16 = state_bf16 ? 1 : 0;
     p.out_bstride = out_batch_stride, p.gates = gates;
+    p.h_pstride = h_pixel_stride, p.out_pstride = out_pixel_stride;
     p.pool_out = pool_out, p.pool_bstride = pool_batch_stride;
     p.hist_points = hist_points, p.hist = hist, p.hist_bstride = hist_batch_stride, p.hist_table = hist_table;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -781,6 +787,18 @@ extern "C" int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const vo
     return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
                          hist_batch_stride, hist_table, h_out, c_out, out, out_batch_stride, gates, save_layout, nullptr,
                          0, stream);
+}
+
+extern "C" int isg_convlstm_cell_fwd_strided(const void* x, const void* h_prev, const void* c_prev,
+                                             const void* packed_fwd, const float* bias, int B, int H, int W, int Cs,
+                                             int F, int dtype, const int32_t* durations, int t,
+                                             const int32_t* hist_points, int hist, long long hist_batch_stride,
+                                             const float* hist_table, void* h_out, int h_pixel_stride, void* c_out,
+                                             void* out, long long out_batch_stride, int out_pixel_stride, void* gates,
+                                             int save_layout, void* stream) {
+    return cell_fwd_impl(x, h_prev, c_prev, packed_fwd, bias, B, H, W, Cs, F, dtype, durations, t, hist_points, hist,
+                         hist_batch_stride, hist_table, h_out, c_out, out, out_batch_stride, gates, save_layout, nullptr,
+                         0, stream, h_pixel_stride, out_pixel_stride);
 }
 
 extern "C" int isg_convlstm_pooled_fwd_supported(int Cs, int F, int dtype, int B, int H, int W, int pool, int hist) {

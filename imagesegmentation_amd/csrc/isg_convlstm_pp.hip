@@ -433,9 +433,11 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                     *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
                     *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
                 }
-                store8(static_cast<T*>(p.h_out) + so, hn);
+                // (pixel indices fit 32 bits, checked on the host: one multiply-add each for the strided outputs)
+                store8(static_cast<T*>(p.h_out) + ((size_t)(unsigned)pixel * (unsigned)p.h_pstride + 8 * half), hn);
                 if (p.out)
-                    store8(static_cast<T*>(p.out) + (size_t)r.b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
+                    store8(static_cast<T*>(p.out) + (size_t)r.b * p.out_bstride +
+                               ((size_t)(unsigned)(gy * p.W + gx) * (unsigned)p.out_pstride + 8 * half), hn);
                 if (p.pool_out) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) psum[c] += (float)(T)hn[c];  // the pool averages the STORED values

@@ -102,9 +102,11 @@ struct ConvParams {
     const float* c_prev;   // [B,H,W,F]
     float* c_out;          // [B,H,W,F]
     int state_bf16;        // c_prev / c_out hold bf16 instead of float (bf16 ping-pong kernels only)
-    void* h_out;           // [B,H,W,F]
-    void* out;             // masked output or null; sample stride out_bstride elements
+    void* h_out;           // [B,H,W,F]; pixel stride h_pstride elements (F = dense; wider: a channel slice of a
+                           // joint buffer, e.g. the next step's [x | h] input)
+    void* out;             // masked output or null; sample stride out_bstride elements, pixel stride out_pstride
     long long out_bstride;
+    int h_pstride, out_pstride;
     void* gates;           // [B,H,W,F,4] (g,i,f,o), or the backward factors [B,H,W,F/2,4,2]; or null
     int save_layout;       // ISG_SAVE_GATES / ISG_SAVE_FACTORS: what `gates` receives
     // pooled output of the ping-pong kernels: means of the masked output over 8 x 8 windows,
@@ -239,8 +241,9 @@ __device__ __forceinline__ void lstm_finish_pixel_with_state(const ConvParams& p
     lstm_pixel<FAST>(z, cp, hn, cn, gs);
     *reinterpret_cast<f32x4*>(p.c_out + so) = f32x4{cn[0], cn[1], cn[2], cn[3]};
     *reinterpret_cast<f32x4*>(p.c_out + so + 4) = f32x4{cn[4], cn[5], cn[6], cn[7]};
-    store8(static_cast<T*>(p.h_out) + so, hn);
-    if (p.out) store8(static_cast<T*>(p.out) + (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + 8 * half, hn);
+    store8(static_cast<T*>(p.h_out) + pixel * p.h_pstride + 8 * half, hn);
+    if (p.out)
+        store8(static_cast<T*>(p.out) + (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * p.out_pstride + 8 * half, hn);
     if (p.gates && p.save_layout == ISG_SAVE_FACTORS) {
         T* fd = static_cast<T*>(p.gates) + pixel * NG + 32 * half;
 #pragma unroll
@@ -293,10 +296,11 @@ __device__ __forceinline__ void lstm_copy_through_tile(const ConvParams& p, int 
                 load4(static_cast<const T*>(p.in1) + o, hv);
             }
             store4(reinterpret_cast<CT*>(p.c_out) + o, cv);
-            store4(static_cast<T*>(p.h_out) + o, hv);
+            store4(static_cast<T*>(p.h_out) + pixel * p.h_pstride + q4 * 4, hv);
             if (p.out) {
                 const float zero[4] = {0.f, 0.f, 0.f, 0.f};
-                store4(static_cast<T*>(p.out) + (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * F_ + q4 * 4, zero);
+                store4(static_cast<T*>(p.out) + (size_t)b * p.out_bstride + ((size_t)gy * p.W + gx) * p.out_pstride + q4 * 4,
+                       zero);
             }
         }
     }

@@ -5,6 +5,7 @@
 // HBM-bound: every element is read once and written once with 16-byte accesses.
 #include <hip/hip_bf16.h>
 
+#include <cstdint>
 #include <mutex>
 
 #include "isg_common.h"
@@ -289,6 +290,40 @@ __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float* __restri
 }
 
 }  // namespace
+
+namespace {
+// 16 bytes per thread: chunk i of pixel p moves from src + p * src_stride + 16 i to dst + p * dst_stride + 16 i
+__global__ __launch_bounds__(256) void copy_channel_slice_kernel(const char* __restrict__ src, long long src_stride,
+                                                                 char* __restrict__ dst, long long dst_stride,
+                                                                 int chunks, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long px = i / chunks;
+        const int c = (int)(i - px * chunks);
+        *reinterpret_cast<uint4*>(dst + px * dst_stride + 16 * c) =
+            *reinterpret_cast<const uint4*>(src + px * src_stride + 16 * c);
+    }
+}
+}  // namespace
+
+extern "C" int isg_copy_channel_slice(const void* src, long long src_pixel_stride, void* dst, long long dst_pixel_stride,
+                                      int slice_bytes, long long npix, void* stream) {
+    ISG_REQUIRE(src && dst, ISG_EINVAL, "isg_copy_channel_slice: null pointer");
+    ISG_REQUIRE(slice_bytes >= 16 && slice_bytes % 16 == 0 && src_pixel_stride >= slice_bytes &&
+                    dst_pixel_stride >= slice_bytes && src_pixel_stride % 16 == 0 && dst_pixel_stride % 16 == 0 &&
+                    (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && npix >= 0,
+                ISG_EINVAL, "isg_copy_channel_slice: the slice, both pixel strides and both addresses are multiples of "
+                "16 bytes, the strides at least the slice (got %d, %lld, %lld)", slice_bytes, src_pixel_stride,
+                dst_pixel_stride);
+    if (npix == 0) return ISG_OK;
+    const int chunks = slice_bytes / 16;
+    const long long total = npix * chunks;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(copy_channel_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char*>(src), src_pixel_stride, static_cast<char*>(dst), dst_pixel_stride, chunks,
+                       total);
+    return isg::check_launch("copy_channel_slice_kernel");
+}
 
 extern "C" int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg, void* stream) {
     ISG_REQUIRE(w && wimg, ISG_EINVAL, "isg_conv32_pack: null argument");

@@ -442,7 +442,7 @@ def saved_shape(B, H, W, F, layout):
 @_timed("cell_fwd")
 def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch_stride=0, save_gates=True,
              h_out=None, c_out=None, gates=None, hist_points=None, pool_out=None, pool_batch_stride=0, pool=1,
-             save_layout=SAVE_GATES):
+             save_layout=SAVE_GATES, h_pixel_stride=None, out_pixel_stride=None):
     """One forward step. x [B,H,W,Cs], h_prev [B,H,W,F] (activation dtype), c_prev float32 - or bfloat16, which
     makes the step read and write the cell state as bfloat16 (where ``state_bf16_supported``; ``c_out`` then
     decides when c_prev is None).
@@ -451,6 +451,8 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
     ``gates`` (or ``save_gates``): the buffer kept for backward, in ``save_layout`` (see ``saved_shape``).
     ``pool_out`` ([B, H/pool, W/pool, F] view with batch stride ``pool_batch_stride``; only where
     ``pooled_fwd_supported``) receives the window means of the emitted output instead of ``out``.
+    ``h_pixel_stride`` / ``out_pixel_stride`` (elements): ``h_out`` / ``out`` are 16-channel slices of wider arrays
+    (their ``data_ptr()`` is the first pixel's first channel); the slices must not overlap what the step reads.
     Returns (h, c, gates)."""
     _need_cuda(x, "x")
     B, H, W, Cs = x.shape
@@ -478,6 +480,16 @@ def cell_fwd(x, h_prev, c_prev, packed, durations=None, t=0, out=None, out_batch
             pool_out.data_ptr(),
             int(pool_batch_stride), _lib.current_stream())
         _lib.check(rc, "isg_convlstm_cell_fwd_pooled")
+        return h, c, gates
+    if h_pixel_stride is not None or out_pixel_stride is not None:
+        assert h_out is not None or h_pixel_stride is None
+        rc = _lib.lib().isg_convlstm_cell_fwd_strided(
+            _lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd), _lib.ptr(packed.bias), B, H, W, Cs,
+            F, dtype_code(x.dtype), _lib.ptr(durations), int(t), pts, packed.hist, pts_stride,
+            _lib.ptr(packed.hist_table), h.data_ptr(), int(h_pixel_stride or F), _lib.ptr(c),
+            out.data_ptr() if out is not None else None, int(out_batch_stride), int(out_pixel_stride or F),
+            _lib.ptr(gates), int(save_layout), _lib.current_stream())
+        _lib.check(rc, "isg_convlstm_cell_fwd_strided")
         return h, c, gates
     rc = _lib.lib().isg_convlstm_cell_fwd(_lib.ptr(x), _lib.ptr(h_prev), _lib.ptr(c_prev), _lib.ptr(packed.fwd),
                                           _lib.ptr(packed.bias), B, H, W, Cs, F, dtype_code(x.dtype),
@@ -672,6 +684,35 @@ def bias_relu_(y, bias):
 
 
 _bias_ws = {}
+
+
+def _pixel_stride_bytes(t):
+    """Bytes between pixels of a channel-slice view [.., n] whose leading dimensions walk pixels densely (each
+    stride = the next one's stride x extent) and whose channels are adjacent; None for any other view."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    ps = t.stride(-2)
+    for d in range(t.dim() - 2):
+        if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            return None
+    return ps * t.element_size()
+
+
+def copy_slice(dst, src):
+    """dst[...] = src[...] for two channel-slice views of NHWC arrays (same shape and dtype): one launch of 16-byte
+    moves where both views walk their pixels with one stride (a torch copy of such views moves 2-byte elements
+    through a generic strided kernel, several times slower); any other pair goes through ``dst.copy_``."""
+    if (dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.shape == src.shape and dst.numel() > 0):
+        ds, ss = _pixel_stride_bytes(dst), _pixel_stride_bytes(src)
+        nbytes = dst.shape[-1] * dst.element_size()
+        if (ds is not None and ss is not None and nbytes % 16 == 0 and ds % 16 == 0 and ss % 16 == 0 and
+                ds >= nbytes and ss >= nbytes and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0):
+            rc = _lib.lib().isg_copy_channel_slice(src.data_ptr(), ss, dst.data_ptr(), ds, nbytes,
+                                                   dst.numel() // dst.shape[-1], _lib.current_stream())
+            _lib.check(rc, "isg_copy_channel_slice")
+            return dst
+    dst.copy_(src)
+    return dst
 
 
 @_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])

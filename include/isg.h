@@ -173,6 +173,20 @@ int isg_convlstm_cell_fwd(const void* x, const void* h_prev, const void* c_prev,
                           long long hist_batch_stride, const float* hist_table, void* h_out, void* c_out, void* out,
                           long long out_batch_stride, void* gates, int save_layout, void* stream);
 
+/* The same step with its two activation outputs as channel slices of wider arrays: pixel p of h_out is written at
+ * h_out + p * h_pixel_stride elements and pixel p of a sample of `out` at out + sample * out_batch_stride +
+ * p * out_pixel_stride (strides multiples of 8 elements, at least F; F = dense, which is isg_convlstm_cell_fwd).
+ * For callers that would otherwise copy the step's h into a joint buffer afterwards: a cell of 16 k filters run as k
+ * groups writes each group's h straight into the next step's [x | h] input and into the joint [.., 16 k] output
+ * (reference convLSTM.py:33, the concat of x and h, and polyrl/a3c/model.py:31-36, whose cell has 32 filters).
+ * The strided destination must not overlap anything the launch reads (x, h_prev, c_prev). */
+int isg_convlstm_cell_fwd_strided(const void* x, const void* h_prev, const void* c_prev, const void* packed_fwd,
+                                  const float* bias, int B, int H, int W, int Cs, int F, int dtype,
+                                  const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                                  long long hist_batch_stride, const float* hist_table, void* h_out,
+                                  int h_pixel_stride, void* c_out, void* out, long long out_batch_stride,
+                                  int out_pixel_stride, void* gates, int save_layout, void* stream);
+
 /* The same step for a caller that only wants the emitted output AVERAGED over pool x pool windows (the head on
  * a coarser grid, see isg_avgpool_fwd): pool_out `dtype` [H/pool][W/pool][F] per sample, samples
  * pool_batch_stride elements apart, zeros for a masked sample; the full-resolution output is never written.
@@ -406,6 +420,13 @@ int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dty
 int isg_relu_bwd_bias_static_init(void);
 int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                              void* stream);
+
+/* A channel slice of an NHWC array copied into a channel slice of another: for each of npix pixels, slice_bytes bytes
+ * from src + p * src_pixel_stride to dst + p * dst_pixel_stride (all in bytes and multiples of 16; the two ranges must
+ * not overlap).  What a cell of 16 k filters run as k groups needs between steps (a group's h joined into the next
+ * step's [x | h] input: reference convLSTM.py:33, polyrl/a3c/model.py:31-36) as one launch of 16-byte moves. */
+int isg_copy_channel_slice(const void* src, long long src_pixel_stride, void* dst, long long dst_pixel_stride,
+                           int slice_bytes, long long npix, void* stream);
 
 /* ---- the encoder's first convolution -------------------------------------------------------------
  * KS x KS taps over a 3-channel image -> cout channels, TensorFlow SAME padding ((KS-1)/2 before, the rest

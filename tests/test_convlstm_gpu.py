@@ -714,6 +714,70 @@ def test_saved_backward_factors_match_the_gate_activations(cs, hist, shape):
     assert float(err.mean()) <= 1e-3
 
 
+@pytest.mark.parametrize("dtype,cs,shape,ragged", [(torch.bfloat16, 48, (3, 12, 40), False),
+                                                   (torch.bfloat16, 32, (2, 19, 37), True),
+                                                   (torch.bfloat16, 64, (2, 9, 33), True),
+                                                   (torch.float32, 20, (2, 9, 37), True)])
+def test_strided_cell_outputs_equal_the_dense_ones(dtype, cs, shape, ragged):
+    """isg_convlstm_cell_fwd_strided: h written as a 16-channel slice of a 48-channel array and the masked output as
+    a slice of a 32-channel one, bit for bit what the dense step writes, with every other channel of the wide arrays
+    left alone - also for finished samples (state copied through, output zero).  Cs = 64 and float32 run the
+    generic kernel, the others the ping-pong kernels."""
+    from imagesegmentation_amd import ops
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell
+    d = dev()
+    B, H, W = shape
+    g = torch.Generator(device=d).manual_seed(cs)
+    cell = ConvLSTMCell([H, W], 16, [3, 3], compute_dtype=dtype, device=d).build(cs, d)
+    packed = cell.packed()
+    x = torch.randn([B, H, W, packed.cs], device=d, generator=g).to(dtype)
+    h = (torch.randn([B, H, W, 16], device=d, generator=g) * 0.5).to(dtype)
+    c = torch.randn([B, H, W, 16], device=d, generator=g) * 1.5
+    durations = torch.tensor([1, 3, 0][:B], dtype=torch.int32, device=d) if ragged else None
+    out_d = torch.full([B, 2, H, W, 16], 7.0, dtype=dtype, device=d)
+    h1, c1, _ = ops.cell_fwd(x, h, c, packed, durations, 1, out=out_d[:, 1], out_batch_stride=2 * H * W * 16,
+                             save_gates=False)
+    wide_h = torch.full([B, H, W, 48], 3.0, dtype=dtype, device=d)
+    wide_out = torch.full([B, 2, H, W, 32], 5.0, dtype=dtype, device=d)
+    h2, c2, _ = ops.cell_fwd(x, h, c, packed, durations, 1, out=wide_out[:, 1, ..., 16:], out_batch_stride=2 * H * W * 32,
+                             out_pixel_stride=32, save_gates=False, h_out=wide_h[..., 32:], h_pixel_stride=48)
+    assert torch.equal(c1, c2)
+    assert torch.equal(wide_h[..., 32:], h1) and bool((wide_h[..., :32] == 3.0).all())
+    assert torch.equal(wide_out[:, 1, ..., 16:], out_d[:, 1])
+    assert bool((wide_out[:, 0] == 5.0).all()) and bool((wide_out[:, 1, ..., :16] == 5.0).all())
+    if ragged:  # sample 0 has ended at t = 1: its h is the previous h, its output zero
+        assert torch.equal(wide_h[0, ..., 32:], h[0]) and bool((wide_out[0, 1, ..., 16:] == 0).all())
+    with pytest.raises(RuntimeError):
+        ops.cell_fwd(x, h, c, packed, durations, 1, save_gates=False, h_out=wide_h[..., 32:], h_pixel_stride=12)
+
+
+def test_channel_slice_copy():
+    """isg_copy_channel_slice (ops.copy_slice) against torch's strided copy: slice to slice, dense to slice, slice to
+    dense, bf16 and float; views it does not cover take the torch copy."""
+    from imagesegmentation_amd import ops
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(5)
+    for dt in (torch.bfloat16, torch.float32):
+        a = torch.randn([3, 7, 9, 48], device=d, generator=g).to(dt)
+        b = torch.randn([3, 7, 9, 32], device=d, generator=g).to(dt)
+        dense = torch.randn([3, 7, 9, 16], device=d, generator=g).to(dt)
+        want = a.clone()
+        want[..., 32:] = b[..., 8:24]
+        ops.copy_slice(a[..., 32:], b[..., 8:24])
+        assert torch.equal(a, want)
+        ops.copy_slice(a[..., 8:24], dense)
+        want[..., 8:24] = dense
+        assert torch.equal(a, want)
+        out = ops.copy_slice(torch.empty([2, 7, 9, 16], dtype=dt, device=d), a[1:, ..., 16:32])
+        assert torch.equal(out, a[1:, ..., 16:32])
+        # a 4-channel bf16 slice is 8 bytes, a transposed view walks pixels with two strides: the torch copy
+        t = torch.zeros([3, 9, 7, 48], dtype=dt, device=d)
+        ops.copy_slice(t.transpose(1, 2)[..., :16], dense)
+        assert torch.equal(t.transpose(1, 2)[..., :16], dense)
+        ops.copy_slice(a[..., :4], dense[..., :4])
+        assert torch.equal(a[..., :4], dense[..., :4])
+
+
 def test_fused_backward_step_against_float64_gate_backward():
     """isg_convlstm_bwd_fused called directly on given factors, c_prev and h: dc_prev and the bias gradient (the
     sum of dY over all pixels) against the float64 gate backward of reference convLSTM.py:40-43 on the same gate
