@@ -67,7 +67,8 @@ SIGNATURES = {
                                      _vp, _int, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _int, _vp]),
     "isg_convlstm_cell_fwd_strided": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _int,
                                              _vp, _int, _ll, _vp, _vp, _int, _vp, _vp, _ll, _int, _vp, _int, _vp]),
-    "isg_copy_channel_slice": (_int, [_vp, _ll, _vp, _ll, _int, _ll, _vp]),
+    "isg_copy_channel_slice": (_int, [_vp, _vp, _vp, _vp, _int, _ll, _ll, _ll, _vp]),
+    "isg_pad_channels": (_int, [_vp, _int, _int, _vp, _int, _ll, _vp]),
     "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),
     "isg_refresh_derived": (_int, [_vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _int, _vp, _vp, _vp, _vp]),
     "isg_convlstm_pooled_fwd_supported": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),

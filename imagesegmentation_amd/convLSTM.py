@@ -733,7 +733,10 @@ class _WideSequenceFunction(torch.autograd.Function):
         xw = torch.empty([max(t_run, 1), B, H, W, cs], dtype=dt, device=dev)
         if cs > C + F - Fh or t_run == 0:
             xw[..., C + F - Fh:] = 0  # padding channels (they meet zero weights, but must be finite)
-        xw[:t_run, ..., :C] = x_seq[:t_run].to(dt)
+        ops.copy_slice(xw[:t_run, ..., :C], x_seq[:t_run] if x_seq.dtype == dt else x_seq[:t_run].to(dt))
+        # (a batch-major source seen time-major: the gradient goes back in the same layout, so that the caller's
+        # transpose and reshape of it are views)
+        ctx.batch_major = T > 1 and B > 1 and x_seq.transpose(0, 1).is_contiguous()
         Hs = [[h0[..., Fh * s:Fh * s + Fh].to(dt).contiguous()] +
               list(torch.empty([t_run, B, H, W, Fh], dtype=dt, device=dev).unbind(0)) for s in range(k)]
         Cs = [[c0[..., Fh * s:Fh * s + Fh].to(torch.float32).contiguous()] +
@@ -861,7 +864,11 @@ class _WideSequenceFunction(torch.autograd.Function):
             dbias[cols] = gw[s][2]
         xd, cd, hd = ctx.in_dtypes
         ctx.saved = ctx.cell = None
-        return (None, None, None, d_xw[..., :C].to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
+        if getattr(ctx, "batch_major", False):
+            d_x = ops.copy_slice(torch.empty([B, T, H, W, C], dtype=dt, device=dev).transpose(0, 1), d_xw[..., :C])
+        else:
+            d_x = ops.copy_slice(torch.empty([T, B, H, W, C], dtype=dt, device=dev), d_xw[..., :C])
+        return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
                 dw_x, dw_h, dbias)
 
 

@@ -292,37 +292,84 @@ __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float* __restri
 }  // namespace
 
 namespace {
-// 16 bytes per thread: chunk i of pixel p moves from src + p * src_stride + 16 i to dst + p * dst_stride + 16 i
-__global__ __launch_bounds__(256) void copy_channel_slice_kernel(const char* __restrict__ src, long long src_stride,
-                                                                 char* __restrict__ dst, long long dst_stride,
-                                                                 int chunks, long long total) {
+struct SliceCopy {
+    const char* src;
+    char* dst;
+    long long src_stride[3], dst_stride[3];  // bytes: outer block, inner block, pixel
+    long long n1, npix;                      // inner blocks per outer block, pixels per inner block
+    int chunks;                              // 16-byte chunks per pixel
+    long long total;
+};
+
+// 16 bytes per thread: chunk c of pixel (i0, i1, q) moves from src + i0 s0 + i1 s1 + q s2 + 16 c to the same place
+// by dst's strides
+__global__ __launch_bounds__(256) void copy_channel_slice_kernel(SliceCopy p) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+        const long long px = i / p.chunks;
+        const int c = (int)(i - px * p.chunks);
+        const long long blk = px / p.npix, q = px - blk * p.npix;
+        const long long i0 = blk / p.n1, i1 = blk - i0 * p.n1;
+        *reinterpret_cast<uint4*>(p.dst + i0 * p.dst_stride[0] + i1 * p.dst_stride[1] + q * p.dst_stride[2] + 16 * c) =
+            *reinterpret_cast<const uint4*>(p.src + i0 * p.src_stride[0] + i1 * p.src_stride[1] + q * p.src_stride[2] + 16 * c);
+    }
+}
+
+// [npix][cin] float or bf16 -> [npix][cout] bf16, channels cin.. zero: thread = one 16-byte run of 8 output channels
+template <typename T>
+__global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__ x, int cin, __bf16* __restrict__ y,
+                                                           int cout, long long total) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const int chunks = cout / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long px = i / chunks;
-        const int c = (int)(i - px * chunks);
-        *reinterpret_cast<uint4*>(dst + px * dst_stride + 16 * c) =
-            *reinterpret_cast<const uint4*>(src + px * src_stride + 16 * c);
+        const int c0 = (int)(i - px * chunks) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = c0 + k < cin ? (__bf16)(float)x[px * cin + c0 + k] : (__bf16)0.0f;
+        *reinterpret_cast<bf16x8*>(y + px * cout + c0) = v;
     }
 }
 }  // namespace
 
-extern "C" int isg_copy_channel_slice(const void* src, long long src_pixel_stride, void* dst, long long dst_pixel_stride,
-                                      int slice_bytes, long long npix, void* stream) {
-    ISG_REQUIRE(src && dst, ISG_EINVAL, "isg_copy_channel_slice: null pointer");
-    ISG_REQUIRE(slice_bytes >= 16 && slice_bytes % 16 == 0 && src_pixel_stride >= slice_bytes &&
-                    dst_pixel_stride >= slice_bytes && src_pixel_stride % 16 == 0 && dst_pixel_stride % 16 == 0 &&
-                    (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && npix >= 0,
-                ISG_EINVAL, "isg_copy_channel_slice: the slice, both pixel strides and both addresses are multiples of "
-                "16 bytes, the strides at least the slice (got %d, %lld, %lld)", slice_bytes, src_pixel_stride,
-                dst_pixel_stride);
+extern "C" int isg_copy_channel_slice(const void* src, const long long* src_strides, void* dst,
+                                      const long long* dst_strides, int slice_bytes, long long n0, long long n1,
+                                      long long npix, void* stream) {
+    ISG_REQUIRE(src && dst && src_strides && dst_strides, ISG_EINVAL, "isg_copy_channel_slice: null pointer");
+    bool ok = slice_bytes >= 16 && slice_bytes % 16 == 0 && n0 >= 0 && n1 >= 0 && npix >= 0 &&
+              (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int k = 0; k < 3 && ok; ++k) ok = src_strides[k] % 16 == 0 && dst_strides[k] % 16 == 0;
+    ok = ok && src_strides[2] >= slice_bytes && dst_strides[2] >= slice_bytes;
+    ISG_REQUIRE(ok, ISG_EINVAL, "isg_copy_channel_slice: the slice, every stride and both addresses are multiples of 16 "
+                "bytes, the pixel strides at least the slice (got slice %d)", slice_bytes);
+    SliceCopy p;
+    p.src = static_cast<const char*>(src), p.dst = static_cast<char*>(dst);
+    for (int k = 0; k < 3; ++k) p.src_stride[k] = src_strides[k], p.dst_stride[k] = dst_strides[k];
+    p.n1 = n1, p.npix = npix, p.chunks = slice_bytes / 16;
+    p.total = n0 * n1 * npix * p.chunks;
+    if (p.total == 0) return ISG_OK;
+    long long blocks = (p.total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(copy_channel_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return isg::check_launch("copy_channel_slice_kernel");
+}
+
+extern "C" int isg_pad_channels(const void* x, int dtype, int cin, void* y, int cout, long long npix, void* stream) {
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_pad_channels: dtype %d", dtype);
+    ISG_REQUIRE(cin >= 1 && cout >= cin && cout % 8 == 0 && npix >= 0, ISG_EINVAL,
+                "isg_pad_channels: 1 <= cin <= cout, cout a multiple of 8 (got %d -> %d)", cin, cout);
     if (npix == 0) return ISG_OK;
-    const int chunks = slice_bytes / 16;
-    const long long total = npix * chunks;
+    ISG_REQUIRE(x && y, ISG_EINVAL, "isg_pad_channels: null pointer");
+    const long long total = npix * (cout / 8);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(copy_channel_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const char*>(src), src_pixel_stride, static_cast<char*>(dst), dst_pixel_stride, chunks,
-                       total);
-    return isg::check_launch("copy_channel_slice_kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(pad_channels_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(x),
+                           cin, static_cast<__bf16*>(y), cout, total);
+    else
+        hipLaunchKernelGGL(pad_channels_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const __bf16*>(x), cin, static_cast<__bf16*>(y), cout, total);
+    return isg::check_launch("pad_channels_kernel");
 }
 
 extern "C" int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg, void* stream) {

@@ -686,33 +686,60 @@ def bias_relu_(y, bias):
 _bias_ws = {}
 
 
-def _pixel_stride_bytes(t):
-    """Bytes between pixels of a channel-slice view [.., n] whose leading dimensions walk pixels densely (each
-    stride = the next one's stride x extent) and whose channels are adjacent; None for any other view."""
-    if t.dim() < 2 or t.stride(-1) != 1:
+def _pixel_levels(views):
+    """The pixel dimensions (all but the last) of same-shaped views, merged where every view walks them with one
+    stride: [(extent, [element stride per view])], innermost first; None when a view's channels are not adjacent."""
+    if any(v.dim() < 2 or v.stride(-1) != 1 for v in views):
         return None
-    ps = t.stride(-2)
-    for d in range(t.dim() - 2):
-        if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
-            return None
-    return ps * t.element_size()
+    levels = []
+    for d in reversed(range(views[0].dim() - 1)):
+        n = views[0].shape[d]
+        if n == 1:
+            continue
+        if levels and all(v.stride(d) == st * levels[-1][0] for v, st in zip(views, levels[-1][1])):
+            levels[-1][0] *= n
+        else:
+            levels.append([n, [v.stride(d) for v in views]])
+    return levels
 
 
 def copy_slice(dst, src):
     """dst[...] = src[...] for two channel-slice views of NHWC arrays (same shape and dtype): one launch of 16-byte
-    moves where both views walk their pixels with one stride (a torch copy of such views moves 2-byte elements
-    through a generic strided kernel, several times slower); any other pair goes through ``dst.copy_``."""
-    if (dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.shape == src.shape and dst.numel() > 0):
-        ds, ss = _pixel_stride_bytes(dst), _pixel_stride_bytes(src)
-        nbytes = dst.shape[-1] * dst.element_size()
-        if (ds is not None and ss is not None and nbytes % 16 == 0 and ds % 16 == 0 and ss % 16 == 0 and
-                ds >= nbytes and ss >= nbytes and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0):
-            rc = _lib.lib().isg_copy_channel_slice(src.data_ptr(), ss, dst.data_ptr(), ds, nbytes,
-                                                   dst.numel() // dst.shape[-1], _lib.current_stream())
-            _lib.check(rc, "isg_copy_channel_slice")
-            return dst
+    moves where the views' pixel dimensions merge into at most three strided levels (a slice of a wider array; a
+    batch-major array seen time-major) - a torch copy of such views moves 2-byte elements through a generic strided
+    kernel, several times slower.  Any other pair goes through ``dst.copy_``.  Returns dst."""
+    if dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.shape == src.shape and dst.numel() > 0:
+        levels = _pixel_levels([dst, src])
+        es = dst.element_size()
+        nbytes = dst.shape[-1] * es
+        if levels is not None and len(levels) <= 3 and nbytes % 16 == 0 and dst.data_ptr() % 16 == 0 and \
+                src.data_ptr() % 16 == 0:
+            levels = levels + [[1, [0, 0]]] * (3 - len(levels))  # innermost first; absent outer levels: one block
+            if levels[0][1] == [0, 0]:
+                levels[0] = [1, [dst.shape[-1], dst.shape[-1]]]
+            ds = [levels[k][1][0] * es for k in (2, 1, 0)]
+            ss = [levels[k][1][1] * es for k in (2, 1, 0)]
+            if all(v % 16 == 0 for v in ds + ss) and ds[2] >= nbytes and ss[2] >= nbytes:
+                import ctypes
+                arr = ctypes.c_longlong * 3
+                rc = _lib.lib().isg_copy_channel_slice(src.data_ptr(), arr(*ss), dst.data_ptr(), arr(*ds), nbytes,
+                                                       levels[2][0], levels[1][0], levels[0][0], _lib.current_stream())
+                _lib.check(rc, "isg_copy_channel_slice")
+                return dst
     dst.copy_(src)
     return dst
+
+
+def pad_channels(x, cout):
+    """x float32 or bfloat16 [.., cin] -> bfloat16 [.., cout] with zero channels cin..: conversion and padding in one
+    pass (an observation for a first encoder layer on the square kernels, ``conv32_pack_padded``)."""
+    assert x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] <= cout and cout % 8 == 0
+    x = x.contiguous()
+    y = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.lib().isg_pad_channels(_lib.ptr(x), dtype_code(x.dtype), int(x.shape[-1]), _lib.ptr(y), int(cout),
+                                     x.numel() // x.shape[-1], _lib.current_stream())
+    _lib.check(rc, "isg_pad_channels")
+    return y
 
 
 @_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])

@@ -31,7 +31,7 @@ from .. import ops, parallel
 from ..convLSTM import ConvLSTMCell, LSTMStateTuple, WideStepper, dynamic_rnn, glorot_uniform_
 from ..optim import FlatAdam
 from ..polyrnn import decode
-from ..polyrnn.Model import _DenseHead, _head_weights, conv2d_same_relu
+from ..polyrnn.Model import _DenseHead, _EncoderChain, _head_weights, conv2d_same_relu, encoder_chain_supported
 
 
 def discount(x, gamma):
@@ -175,7 +175,14 @@ class LSTMPolicy:
         # [R, H, W, C] -> [R, H, W, 32]
         # the same layer routine as the polygon-RNN encoder: 32 -> 32 layers run on the conv32 kernels in bf16
         dt = self.compute_dtype
-        y = x.to(dt).contiguous()
+        w0 = self.convs[0][0]
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and ops.conv32_padded_supported(w0, dt, x.device):
+            # conversion to the compute type and the zero channels of the padded first layer in one pass
+            y = ops.pad_channels(x, w0.shape[3])
+        else:
+            y = x.to(dt).contiguous()
+        if torch.is_grad_enabled() and encoder_chain_supported(y, self.convs, dt):
+            return _EncoderChain.apply(y, *[p for wb in self.convs for p in wb]).contiguous()
         for w, b in self.convs:
             y = conv2d_same_relu(y, w, b, dt)
         return y.contiguous()

@@ -116,7 +116,7 @@ class _Conv32Padded(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_hwio, bias):
         ks, cin, c = w_hwio.shape[0], w_hwio.shape[2], w_hwio.shape[3]
-        xp = F.pad(x, (0, c - cin)).contiguous()
+        xp = x.contiguous() if x.shape[-1] == c else ops.pad_channels(x, c)  # (c channels: padded by the caller)
         y = ops.conv32(xp, ops.conv32_pack_padded(w_hwio), bias.detach().float().contiguous(), ks, relu=True)
         ctx.save_for_backward(xp, y)
         ctx.ks, ctx.cin, ctx.dtypes = ks, cin, (w_hwio.dtype, bias.dtype)
@@ -131,17 +131,25 @@ class _Conv32Padded(torch.autograd.Function):
 
 
 class _EncoderChain(torch.autograd.Function):
-    """A whole encoder of hand-written layers - the first on the isg_conv_in kernels, the others on isg_conv32 /
-    isg_conv16 - as one autograd node (reference polyrnn/History2LargeExperiment.py:15-22,
-    polyrnn/RNNConvExperiment.py:14-22).  Seen as a chain, the backward pass needs the separate ReLU-mask and
+    """A whole encoder of hand-written layers - the first on the isg_conv_in kernels (a 3-channel image) or, with its
+    input padded with zero channels, on isg_conv32 / isg_conv16 (reference polyrl/a3c/model.py:19-20: image +
+    history frames), the others on isg_conv32 / isg_conv16 - as one autograd node (reference
+    polyrnn/History2LargeExperiment.py:15-22, polyrnn/RNNConvExperiment.py:14-22).  Seen as a chain, the backward pass needs the separate ReLU-mask and
     bias-gradient pass only for the top layer: every data gradient lands on the ReLU output of the layer below
     and applies that layer's mask and sums its bias gradient in its own epilogue (isg_conv32_masked)."""
 
     @staticmethod
     def forward(ctx, x3, *params):
         ws, bs = params[0::2], params[1::2]
-        x4 = ops.conv_in_pad_image(x3.contiguous())
-        ys = [ops.conv_in_fwd(x4, ops.conv_in_pack(ws[0]), bs[0].detach().float().contiguous(), ws[0].shape[0], relu=True)]
+        ctx.padded_first = not ops.conv_in_supported(ws[0], x3.dtype, x3.device)
+        if ctx.padded_first:
+            x4 = x3.contiguous() if x3.shape[-1] == ws[0].shape[3] else ops.pad_channels(x3, ws[0].shape[3])
+            ys = [ops.conv32(x4, ops.conv32_pack_padded(ws[0]), bs[0].detach().float().contiguous(), ws[0].shape[0],
+                             relu=True)]
+        else:
+            x4 = ops.conv_in_pad_image(x3.contiguous())
+            ys = [ops.conv_in_fwd(x4, ops.conv_in_pack(ws[0]), bs[0].detach().float().contiguous(), ws[0].shape[0],
+                                  relu=True)]
         for w, b in zip(ws[1:], bs[1:]):
             ys.append(ops.conv32(ys[-1], ops.conv32_pack(w), b.detach().float().contiguous(), w.shape[0], relu=True))
         ctx.save_for_backward(x4, *ys, *ws)
@@ -172,18 +180,22 @@ class _EncoderChain(torch.autograd.Function):
             hand(2 * k + 1, bs[k], dbias, ctx.dtypes[2 * k + 1])
             dz, dbias = ops.conv32_masked(dz, ops.conv32_pack(ws[k], data_gradient=True), ys[k - 1], ks,
                                           dbias_out=dst(bs[k - 1]))
-        hand(0, ws[0], ops.conv_in_wgrad(x4, dz, ws[0].shape[0], out=dst(ws[0])), ctx.dtypes[0])
+        if ctx.padded_first:  # (the padded kernel's gradient has rows for the zero channels too: no sink for it)
+            grads[0] = ops.conv32_wgrad(x4, dz, ws[0].shape[0])[:, :, :ws[0].shape[2]].to(ctx.dtypes[0])
+        else:
+            hand(0, ws[0], ops.conv_in_wgrad(x4, dz, ws[0].shape[0], out=dst(ws[0])), ctx.dtypes[0])
         hand(1, bs[0], dbias, ctx.dtypes[1])
         return (None,) + tuple(grads)
 
 
 def encoder_chain_supported(x_nhwc, encoder, dtype):
     """Whether ``_EncoderChain`` takes this encoder: an input that needs no gradient, a first layer for the
-    isg_conv_in kernels and at least one more layer, all of those for the isg_conv32 / isg_conv16 kernels."""
+    isg_conv_in kernels (or, padded, for the square ones) and at least one more layer, all of those for the isg_conv32 / isg_conv16 kernels."""
     if x_nhwc.requires_grad or len(encoder) < 2 or x_nhwc.dtype != dtype or os.environ.get("ISG_NO_ENCODER_CHAIN"):
         return False  # (the environment switch: layer-by-layer nodes, for A/B runs)
     (w0, _), rest = encoder[0], encoder[1:]
-    return ops.conv_in_supported(w0, dtype, x_nhwc.device) and \
+    first = ops.conv_in_supported(w0, dtype, x_nhwc.device) or ops.conv32_padded_supported(w0, dtype, x_nhwc.device)
+    return first and \
         all(ops.conv32_supported(w, dtype, x_nhwc.device) and w.shape[2] == w0.shape[3] for w, _ in rest)
 
 

@@ -421,12 +421,19 @@ int isg_relu_bwd_bias_static_init(void);
 int isg_relu_bwd_bias_static(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                              void* stream);
 
-/* A channel slice of an NHWC array copied into a channel slice of another: for each of npix pixels, slice_bytes bytes
- * from src + p * src_pixel_stride to dst + p * dst_pixel_stride (all in bytes and multiples of 16; the two ranges must
- * not overlap).  What a cell of 16 k filters run as k groups needs between steps (a group's h joined into the next
- * step's [x | h] input: reference convLSTM.py:33, polyrl/a3c/model.py:31-36) as one launch of 16-byte moves. */
-int isg_copy_channel_slice(const void* src, long long src_pixel_stride, void* dst, long long dst_pixel_stride,
-                           int slice_bytes, long long npix, void* stream);
+/* A channel slice of an NHWC array copied into a channel slice of another: slice_bytes bytes of each pixel
+ * (i0, i1, q), i0 < n0, i1 < n1, q < npix, from src + i0 s[0] + i1 s[1] + q s[2] (s = src_strides, HOST array of 3,
+ * bytes) to the same place by dst_strides; every stride, the slice and both addresses multiples of 16, the two ranges
+ * must not overlap.  What a cell of 16 k filters run as k groups needs between steps (a group's h joined into the
+ * next step's [x | h] input: reference convLSTM.py:33, polyrl/a3c/model.py:31-36) and around a sequence (batch-major
+ * features into the time-major joint input and back: the two outer strides) as one launch of 16-byte moves. */
+int isg_copy_channel_slice(const void* src, const long long* src_strides, void* dst, const long long* dst_strides,
+                           int slice_bytes, long long n0, long long n1, long long npix, void* stream);
+
+/* x `dtype` (float or bf16) [npix][cin] -> y bf16 [npix][cout], channels cin.. zero: conversion and padding of an
+ * observation (image + history frames, reference polyrl/a3c/model.py:19-20) in one pass, for a first encoder layer
+ * that runs on the 32 -> 32 (16 -> 16) kernels with zero weight rows (isg_conv32_pack_padded).  cout a multiple of 8. */
+int isg_pad_channels(const void* x, int dtype, int cin, void* y, int cout, long long npix, void* stream);
 
 /* ---- the encoder's first convolution -------------------------------------------------------------
  * KS x KS taps over a 3-channel image -> cout channels, TensorFlow SAME padding ((KS-1)/2 before, the rest

@@ -770,12 +770,33 @@ def test_channel_slice_copy():
         assert torch.equal(a, want)
         out = ops.copy_slice(torch.empty([2, 7, 9, 16], dtype=dt, device=d), a[1:, ..., 16:32])
         assert torch.equal(out, a[1:, ..., 16:32])
-        # a 4-channel bf16 slice is 8 bytes, a transposed view walks pixels with two strides: the torch copy
-        t = torch.zeros([3, 9, 7, 48], dtype=dt, device=d)
-        ops.copy_slice(t.transpose(1, 2)[..., :16], dense)
-        assert torch.equal(t.transpose(1, 2)[..., :16], dense)
+        # batch-major features into a time-major joint buffer and back (three strided levels)
+        feats = torch.randn([4, 5, 6, 8, 32], device=d, generator=g).to(dt)          # [B, T, H, W, C]
+        xw = torch.zeros([5, 4, 6, 8, 48], dtype=dt, device=d)                       # [T, B, H, W, C + 16]
+        ops.copy_slice(xw[:3, ..., :32], feats.transpose(0, 1)[:3])
+        assert torch.equal(xw[:3, ..., :32], feats.transpose(0, 1)[:3]) and bool((xw[3:] == 0).all())
+        assert bool((xw[..., 32:] == 0).all())
+        back = ops.copy_slice(torch.empty([4, 5, 6, 8, 32], dtype=dt, device=d).transpose(0, 1), xw[..., :32])
+        assert torch.equal(back[:3], feats.transpose(0, 1)[:3]) and bool((back[3:] == 0).all())
+        # a 4-channel bf16 slice is 8 bytes; a view with four strided levels: the torch copy
         ops.copy_slice(a[..., :4], dense[..., :4])
         assert torch.equal(a[..., :4], dense[..., :4])
+        big = torch.zeros([6, 14, 18, 48], dtype=dt, device=d)
+        ops.copy_slice(big[::2, ::2, ::2, :16], dense)
+        assert torch.equal(big[::2, ::2, ::2, :16], dense)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pad_channels_converts_and_pads_in_one_pass(dtype):
+    """isg_pad_channels against convert + F.pad: 5 or 13 channels into 32 or 16, float and bf16 sources."""
+    from imagesegmentation_amd import ops
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(9)
+    for cin, cout in ((5, 32), (13, 16), (16, 16), (3, 8)):
+        x = torch.randn([3, 7, 9, cin], device=d, generator=g).to(dtype)
+        got = ops.pad_channels(x, cout)
+        want = torch.nn.functional.pad(x.to(torch.bfloat16), (0, cout - cin))
+        assert got.dtype == torch.bfloat16 and got.is_contiguous() and torch.equal(got, want)
 
 
 def test_fused_backward_step_against_float64_gate_backward():
