@@ -27,11 +27,16 @@ def run():
     trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0)
     trainer.process(images, polygons)
     torch.cuda.synchronize()
-    for _ in range(3):
+    times = []
+    for _ in range(int(os.environ.get("ISG_A3C_UPDATES", "3"))):
         t0 = time.perf_counter()
         trainer.process(images, polygons)
         torch.cuda.synchronize()
-        print("update ms %.3f" % ((time.perf_counter() - t0) * 1e3))
+        times.append((time.perf_counter() - t0) * 1e3)
+        print("update ms %.3f" % times[-1])
+    if len(times) > 4:
+        tail = sorted(times[2:])
+        print("median of the last %d: %.3f ms" % (len(tail), tail[len(tail) // 2]))
 
 
 if __name__ == "__main__":
