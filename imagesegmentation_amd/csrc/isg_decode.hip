@@ -400,6 +400,114 @@ extern "C" int isg_decode_step(const void* logits, int rows, int cols, int dtype
     return isg::check_launch("decode_step_kernel");
 }
 
+namespace {
+// one thread per sample: what the decode loop starts from
+__global__ __launch_bounds__(256) void decode_begin_kernel(const int32_t* __restrict__ vt, const int32_t* __restrict__ nvt,
+                                                           int B, int vmax, int hist, int T, int32_t* __restrict__ close_xy,
+                                                           int32_t* __restrict__ pts0, int32_t* __restrict__ pts,
+                                                           int32_t* __restrict__ required, int32_t* __restrict__ durations,
+                                                           int32_t* __restrict__ predicted) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int n = nvt[b];
+    const int frames = hist > 0 ? hist : 1;
+    for (int i = 0; i < frames; ++i) {
+        int v = 0;
+        if (n > 0) {
+            v = (n - hist + i) % n;
+            v = v < 0 ? v + n : v;
+        }
+        const int x = vt[((size_t)b * vmax + v) * 2], y = vt[((size_t)b * vmax + v) * 2 + 1];
+        if (i == 0) close_xy[2 * b] = x, close_xy[2 * b + 1] = y;
+        if (i < hist) {
+            const size_t o = ((size_t)b * hist + i) * 2;
+            pts0[o] = x, pts0[o + 1] = y, pts[o] = x, pts[o + 1] = y;
+        }
+    }
+    required[b] = 1, durations[b] = 0;
+    for (int i = 0; i < 2 * T; ++i) predicted[(size_t)b * 2 * T + i] = 0;
+}
+
+// one thread per (sample, output vertex): the predicted polygon as the rasteriser takes it
+__global__ __launch_bounds__(256) void decode_polygons_kernel(const int32_t* __restrict__ predicted,
+                                                              const int32_t* __restrict__ durations,
+                                                              const int32_t* __restrict__ pts0, int B, int T, int hist,
+                                                              int prepend, int by_duration, int scale, int vmax,
+                                                              int32_t* __restrict__ vp, int32_t* __restrict__ count) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * vmax) return;
+    const int b = (int)(i / vmax), j = (int)(i - (long long)b * vmax);
+    const int lead = prepend ? hist : 0;
+    int x = 0, y = 0;
+    if (j < lead) {
+        x = pts0[((size_t)b * hist + j) * 2], y = pts0[((size_t)b * hist + j) * 2 + 1];
+    } else if (j - lead < T) {
+        x = predicted[((size_t)b * T + (j - lead)) * 2] * scale, y = predicted[((size_t)b * T + (j - lead)) * 2 + 1] * scale;
+    }
+    vp[i * 2] = x, vp[i * 2 + 1] = y;
+    if (j == 0) count[b] = (by_duration ? durations[b] : T) + lead;
+}
+
+// out[r][c] = sum over slices of part[s][r][c] + bias[c], in the order of the slices
+template <typename T>
+__global__ __launch_bounds__(256) void sum_slices_bias_kernel(const float* __restrict__ part, int slices, long long n,
+                                                              int cols, const T* __restrict__ bias, T* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.0f;
+    for (int s = 0; s < slices; ++s) v += part[(long long)s * n + i];
+    out[i] = (T)(v + (float)bias[i % cols]);
+}
+}  // namespace
+
+extern "C" int isg_decode_begin(const int32_t* true_vertices, const int32_t* num_true, int B, int vmax, int hist, int T,
+                                int32_t* close_xy, int32_t* first_points, int32_t* history_points, int32_t* required,
+                                int32_t* durations, int32_t* predicted, void* stream) {
+    ISG_REQUIRE(B >= 0 && vmax >= 1 && hist >= 0 && T >= 1, ISG_EINVAL, "isg_decode_begin: B=%d vmax=%d hist=%d T=%d", B,
+                vmax, hist, T);
+    if (B == 0) return ISG_OK;
+    ISG_REQUIRE(true_vertices && num_true && close_xy && required && durations && predicted &&
+                    (hist == 0 || (first_points && history_points)), ISG_EINVAL, "isg_decode_begin: null pointer");
+    hipLaunchKernelGGL(decode_begin_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       true_vertices, num_true, B, vmax, hist, T, close_xy, first_points, history_points, required,
+                       durations, predicted);
+    return isg::check_launch("decode_begin_kernel");
+}
+
+extern "C" int isg_decode_polygons(const int32_t* predicted, const int32_t* durations, const int32_t* first_points, int B,
+                                   int T, int hist, int prepend_history, int slice_by_duration, int scale, int vmax,
+                                   int32_t* polygons, int32_t* counts, void* stream) {
+    ISG_REQUIRE(B >= 0 && T >= 1 && hist >= 0 && scale >= 1 && vmax >= T + (prepend_history ? hist : 0), ISG_EINVAL,
+                "isg_decode_polygons: B=%d T=%d hist=%d scale=%d vmax=%d", B, T, hist, scale, vmax);
+    if (B == 0) return ISG_OK;
+    ISG_REQUIRE(predicted && durations && polygons && counts && (!prepend_history || hist == 0 || first_points),
+                ISG_EINVAL, "isg_decode_polygons: null pointer");
+    const long long n = (long long)B * vmax;
+    hipLaunchKernelGGL(decode_polygons_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), predicted, durations, first_points, B, T, hist,
+                       prepend_history ? 1 : 0, slice_by_duration ? 1 : 0, scale, vmax, polygons, counts);
+    return isg::check_launch("decode_polygons_kernel");
+}
+
+extern "C" int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype,
+                                   void* out, void* stream) {
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_sum_slices_bias: dtype %d", dtype);
+    ISG_REQUIRE(slices >= 1 && rows >= 0 && cols >= 1, ISG_EINVAL, "isg_sum_slices_bias: slices=%d rows=%d cols=%d", slices,
+                rows, cols);
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(part && bias && out, ISG_EINVAL, "isg_sum_slices_bias: null pointer");
+    const long long n = (long long)rows * cols;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(sum_slices_bias_kernel<float>, grid, block, 0, s, part, slices, n, cols,
+                           static_cast<const float*>(bias), static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(sum_slices_bias_kernel<__hip_bfloat16>, grid, block, 0, s, part, slices, n, cols,
+                           static_cast<const __hip_bfloat16*>(bias), static_cast<__hip_bfloat16*>(out));
+    return isg::check_launch("sum_slices_bias_kernel");
+}
+
 extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T,
                                     int P, double* out4, void* stream) {
     ISG_REQUIRE(B >= 0 && T >= 0 && P >= 1, ISG_EINVAL, "isg_sequence_metrics: bad shape B=%d T=%d P=%d", B, T, P);

@@ -566,7 +566,9 @@ class Model:
         elif flat.dtype != w.dtype:
             # decode loops call the head once per step with unchanged weights: convert them once
             wc, bc = _head_weights(flat.dtype, w, b, self._head_cache)
-            logits = torch.addmm(bc, flat, wc)
+            logits = decode.dense_few_rows(flat, wc, bc) if not os.environ.get("ISG_NO_SPLIT_HEAD") else None
+            if logits is None:
+                logits = torch.addmm(bc, flat, wc)
         else:
             logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
@@ -815,17 +817,9 @@ class Model:
         T, hist, dev = self.max_timesteps, self.history_length, self.device
         with torch.no_grad():
             features = self.encode(images_dev)
-            n = nvt.long()[:, None]
             # frame i of the first step shows true_vertices[len - hist + i] (create_history with
             # end_idx = len(v) - 1, Model.py:224-226); the closing vertex is true_vertices[-hist] (Model.py:240)
-            first = (n - hist + torch.arange(max(hist, 1), device=dev)[None, :]) % n
-            picked = vt.gather(1, first[:, :, None].expand(-1, -1, 2))
-            close = picked[:, 0].contiguous()
-            pts0 = picked[:, :hist].contiguous()
-            pts = pts0.clone()
-            required = torch.ones([B], dtype=torch.int32, device=dev)
-            durations = torch.zeros([B], dtype=torch.int32, device=dev)
-            predicted = torch.zeros([B, T, 2], dtype=torch.int32, device=dev)
+            close, pts0, pts, required, durations, predicted = decode.decode_begin(vt, nvt, hist, T)
             stepper = RecurrentStepper(self.rnn, features, hist)
             for i in range(T):
                 out = stepper.step(pts, durations=required, t=0)
@@ -899,14 +893,14 @@ class Model:
         polyrnn/Model.py:252-260): int32 [B, 2 T + 3] = predicted vertices, durations, intersection, union."""
         B, T = predicted.shape[0], self.max_timesteps
         P, hist = self.prediction_size, self.history_length
-        count = durations if self.iou_slice_by_duration else torch.full_like(durations, T)
-        vp = predicted * (P // self.head_size)
-        if self.iou_prepend_history and hist > 0:  # the polygon starts with the last `hist` true vertices
-            vp = torch.cat([pts0, vp], dim=1)
-            count = count + hist
-        vmax = max(vp.shape[1], vt.shape[1], util.VMAX_DEFAULT)
-        pad = lambda v: torch.nn.functional.pad(v, (0, 0, 0, vmax - v.shape[1])).contiguous()
-        inter, union = util.raster_iou(pad(vp), count.contiguous(), pad(vt), nvt, P)
+        # (the polygon starts with the last `hist` true vertices where the experiment says so)
+        lead = hist if self.iou_prepend_history else 0
+        vmax = max(T + lead, vt.shape[1], util.VMAX_DEFAULT)
+        vp, count = decode.decode_polygons(predicted, durations, pts0, P // self.head_size, lead > 0,
+                                           self.iou_slice_by_duration, vmax)
+        if vt.shape[1] != vmax:
+            vt = torch.nn.functional.pad(vt, (0, 0, 0, vmax - vt.shape[1])).contiguous()
+        inter, union = util.raster_iou(vp, count, vt, nvt, P)
         return torch.cat([predicted.reshape(B, -1), durations[:, None], inter[:, None], union[:, None]], dim=1)
 
     def decode(self, images, true_vertices):

@@ -160,6 +160,60 @@ def sample_actions(logits, seed, grid_side, row_offset=0, row_offset_dev=None, o
     return out
 
 
+def decode_begin(true_vertices, num_true, hist, steps):
+    """isg_decode_begin: what the decode loop starts from, one launch (reference polyrnn/Model.py:218-230).
+    true_vertices int32 [B, vmax, 2], num_true int32 [B] -> (close_xy [B,2], first history points [B,hist,2], the
+    loop's own copy of them, required [B] = 1, durations [B] = 0, predicted [B,steps,2] = 0), all int32."""
+    B, vmax = true_vertices.shape[0], true_vertices.shape[1]
+    dev = true_vertices.device
+    assert true_vertices.dtype == torch.int32 and num_true.dtype == torch.int32
+    new = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    close, pts0, pts = new(B, 2), new(B, hist, 2), new(B, hist, 2)
+    required, durations, predicted = new(B), new(B), new(B, steps, 2)
+    rc = _lib.lib().isg_decode_begin(_lib.ptr(true_vertices.contiguous()), _lib.ptr(num_true.contiguous()), B, vmax,
+                                     int(hist), int(steps), _lib.ptr(close), _lib.ptr(pts0) if hist else None,
+                                     _lib.ptr(pts) if hist else None, _lib.ptr(required), _lib.ptr(durations),
+                                     _lib.ptr(predicted), _lib.current_stream())
+    _lib.check(rc, "isg_decode_begin")
+    return close, pts0, pts, required, durations, predicted
+
+
+def decode_polygons(predicted, durations, first_points, scale, prepend_history, slice_by_duration, vmax):
+    """isg_decode_polygons: the decoded polygons as the rasteriser takes them (reference polyrnn/Model.py:252-260):
+    (polygons int32 [B, vmax, 2], counts int32 [B])."""
+    B, T = predicted.shape[0], predicted.shape[1]
+    hist = first_points.shape[1]
+    vp = torch.empty([B, vmax, 2], dtype=torch.int32, device=predicted.device)
+    count = torch.empty([B], dtype=torch.int32, device=predicted.device)
+    rc = _lib.lib().isg_decode_polygons(_lib.ptr(predicted), _lib.ptr(durations), _lib.ptr(first_points) if hist else None,
+                                        B, T, hist, int(bool(prepend_history)), int(bool(slice_by_duration)), int(scale),
+                                        int(vmax), _lib.ptr(vp), _lib.ptr(count), _lib.current_stream())
+    _lib.check(rc, "isg_decode_polygons")
+    return vp, count
+
+
+def dense_few_rows(flat, w, b, slices=8):
+    """flat [M, K] @ w [K, N] + b in the operands' type for a handful of rows (a decode step's head): one library
+    GEMM has M N / tile output tiles for 256 CUs, so the reduction axis is cut into ``slices`` batched GEMMs with
+    float results, summed with the bias by one launch (isg_sum_slices_bias).  None when the shape does not call for
+    it (the caller's plain GEMM then)."""
+    M, K = flat.shape
+    N = w.shape[1]
+    if not (flat.is_cuda and flat.dtype == torch.bfloat16 and w.dtype == flat.dtype and flat.is_contiguous() and
+            w.is_contiguous() and M * N <= (1 << 16) and K % (slices * 8) == 0 and K // slices >= 512):
+        return None
+    try:
+        part = torch.bmm(flat.view(M, slices, K // slices).transpose(0, 1), w.view(slices, K // slices, N),
+                         out_dtype=torch.float32)
+    except TypeError:  # (a torch without float32 results from a bf16 batched GEMM)
+        return None
+    out = torch.empty([M, N], dtype=flat.dtype, device=flat.device)
+    rc = _lib.lib().isg_sum_slices_bias(_lib.ptr(part), slices, M, N, _lib.ptr(b.contiguous()), dtype_code(out.dtype),
+                                        _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_sum_slices_bias")
+    return out
+
+
 def decode_step(logits, grid_side, end_token, close_xy, required, durations, predicted, step, history_points):
     """isg_decode_step: argmax of every row, then the decode loop's bookkeeping (stop rule, predicted polygon,
     history points of the next step) on the device.  logits [B, K]; all other tensors int32 and updated in

@@ -329,6 +329,28 @@ int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsign
                        unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
                        int32_t* out_xy, void* stream);
 
+/* What the reference's decode loop starts from (polyrnn/Model.py:218-230), for every sample in one launch: with n =
+ * num_true[r] and frame i of the first step showing true vertex (n - hist + i) mod n (create_history with end_idx =
+ * len(v) - 1), first_points = history_points = those hist points, close_xy = frame 0's point (the closing vertex,
+ * Model.py:240; hist = 0: true vertex 0), required = 1, durations = 0, predicted = 0.
+ * true_vertices int32 [B][vmax][2], num_true int32 [B]; outputs as isg_decode_step takes them. */
+int isg_decode_begin(const int32_t* true_vertices, const int32_t* num_true, int B, int vmax, int hist, int T,
+                     int32_t* close_xy, int32_t* first_points, int32_t* history_points, int32_t* required,
+                     int32_t* durations, int32_t* predicted, void* stream);
+
+/* The decoded polygons as the rasteriser takes them (polyrnn/Model.py:252-260): polygons int32 [B][vmax][2] = the
+ * first_points (when prepend_history) followed by predicted * scale, zero beyond; counts[r] = (durations[r] when
+ * slice_by_duration, else T) + the prepended points. */
+int isg_decode_polygons(const int32_t* predicted, const int32_t* durations, const int32_t* first_points, int B, int T,
+                        int hist, int prepend_history, int slice_by_duration, int scale, int vmax, int32_t* polygons,
+                        int32_t* counts, void* stream);
+
+/* out `dtype` [rows][cols] = sum over s < slices of part[s][rows][cols] (float) + bias[cols] (`dtype`): closes a dense
+ * layer whose reduction axis was cut into `slices` batched GEMMs with float results - the decode loop's head at a
+ * handful of rows (polyrnn/Model.py:231-249 runs it once per vertex), where one GEMM has too few output tiles. */
+int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype, void* out,
+                        void* stream);
+
 /* One iteration of the reference's autoregressive decode loop (polyrnn/Model.py:231-249; end-token variant
  * polyrnn/EndTokenExperiment.py:158-170, EndTokenDeepExperiment_2.py:150-170) for every sample, in one launch
  * after the head, with no host round trip.  Per row r of logits [rows][cols]:
