@@ -356,3 +356,64 @@ def test_sequence_loss_in_two_launches_against_the_oracle(B, T, P, end_token, dt
     loss2.backward(gradient=up)
     assert abs(loss2.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
     assert torch.allclose(tz2.grad.float(), tz.grad.float(), rtol=0, atol=max(tol, 1e-7))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hist", [0, 1, 2, 5])
+def test_decode_begin_and_polygon_assembly_follow_the_host_loop(hist):
+    """isg_decode_begin / isg_decode_polygons against the reference's own arithmetic (polyrnn/Model.py:218-230,
+    252-260) written with numpy: the first history frames are the last `hist` true vertices (indices taken modulo the
+    polygon's length, also where the polygon is shorter than the history), the closing vertex is frame 0's, and the
+    rasterised polygon is those frames followed by the predicted vertices scaled to the image."""
+    from imagesegmentation_amd.polyrnn import decode
+    rs = np.random.RandomState(3 + hist)
+    B, vmax, T = 9, 16, 6
+    nvt = rs.randint(3, vmax + 1, [B]).astype(np.int32)
+    nvt[0] = 3
+    vt = rs.randint(0, 28, [B, vmax, 2]).astype(np.int32)
+    d = "cuda:0"
+    close, pts0, pts, required, durations, predicted = decode.decode_begin(torch.tensor(vt, device=d),
+                                                                            torch.tensor(nvt, device=d), hist, T)
+    want = np.zeros([B, max(hist, 1), 2], np.int32)
+    for b in range(B):
+        for i in range(max(hist, 1)):
+            want[b, i] = vt[b, (int(nvt[b]) - hist + i) % int(nvt[b])]
+    assert np.array_equal(close.cpu().numpy(), want[:, 0])
+    assert np.array_equal(pts0.cpu().numpy(), want[:, :hist]) and np.array_equal(pts.cpu().numpy(), want[:, :hist])
+    assert pts.data_ptr() != pts0.data_ptr() or hist == 0
+    assert bool((required == 1).all()) and bool((durations == 0).all()) and bool((predicted == 0).all())
+    assert tuple(predicted.shape) == (B, T, 2)
+
+    pred = rs.randint(0, 28, [B, T, 2]).astype(np.int32)
+    dur = rs.randint(0, T + 1, [B]).astype(np.int32)
+    for prepend in (False, True):
+        for by_duration in (False, True):
+            vp, count = decode.decode_polygons(torch.tensor(pred, device=d), torch.tensor(dur, device=d), pts0, 8,
+                                               prepend and hist > 0, by_duration, 24)
+            lead = hist if prepend else 0
+            ref = np.zeros([B, 24, 2], np.int32)
+            ref[:, :lead] = want[:, :lead]
+            ref[:, lead:lead + T] = pred * 8
+            assert np.array_equal(vp.cpu().numpy(), ref)
+            assert np.array_equal(count.cpu().numpy(), (dur if by_duration else np.full([B], T)) + lead)
+
+
+@pytest.mark.gpu
+def test_head_at_a_handful_of_rows_equals_the_library_gemm():
+    """decode.dense_few_rows (reduction axis cut into batched GEMMs with float partial sums, one summing launch) against
+    float64: no further from it than the library's one-GEMM result; shapes it does not take return None."""
+    from imagesegmentation_amd.polyrnn import decode
+    d = "cuda:0"
+    g = torch.Generator(device=d).manual_seed(11)
+    M, K, N = 16, 12544, 785
+    flat = (torch.randn([M, K], device=d, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn([K, N], device=d, generator=g) * 0.01).to(torch.bfloat16)
+    b = torch.randn([N], device=d, generator=g).to(torch.bfloat16)
+    got = decode.dense_few_rows(flat, w, b)
+    assert got is not None and got.dtype == torch.bfloat16 and tuple(got.shape) == (M, N)
+    ref = flat.double() @ w.double() + b.double()
+    one = torch.addmm(b, flat, w)
+    err, err_one = float((got.double() - ref).abs().max()), float((one.double() - ref).abs().max())
+    assert err <= max(err_one, 2.0 ** -8 * float(ref.abs().max()))
+    assert decode.dense_few_rows(flat.float(), w.float(), b.float()) is None
+    assert decode.dense_few_rows(flat[:, :1000].contiguous(), w[:1000].contiguous(), b) is None
