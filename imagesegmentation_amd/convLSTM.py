@@ -792,8 +792,11 @@ class _WideSequenceFunction(torch.autograd.Function):
         if fused:
             dc_next = [torch.empty_like(g) for g in dc_state]
             dh_next0 = torch.empty_like(dh_state[0])
-        if d_out is not None:  # group-major, one copy for the whole sequence
-            d_out_g = d_out.to(dt).reshape(B, T, H, W, k, Fh).permute(4, 0, 1, 2, 3, 5).contiguous()
+        if d_out is not None:  # group-major: one launch of 16-byte moves per group for the whole sequence
+            d_out_c = d_out if d_out.dtype == dt else d_out.to(dt)
+            d_out_g = torch.empty([k, B, T, H, W, Fh], dtype=dt, device=dev)
+            for s in range(k):
+                ops.copy_slice(d_out_g[s], d_out_c[..., Fh * s:Fh * s + Fh])
         else:
             d_out_g = torch.zeros([k, B, T, H, W, Fh], dtype=dt, device=dev)
         # the gradient of the joint input [x | h[16:]] of every step, written in place by the data-gradient launches:
