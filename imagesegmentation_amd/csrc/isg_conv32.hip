@@ -86,8 +86,13 @@ struct Conv32Params {
 constexpr int kMaskedMaxBlocks = 1024;
 
 // MASK: no bias, no ReLU; the epilogue applies `mask` and sums what it keeps (see the top of the file).
+// waves per SIMD the register allocation aims at: two workgroups of 8 waves per CU wherever the LDS image leaves room
+// for two (128 registers per lane), else one
+template <int KS, int CH>
+constexpr int conv32_min_blocks() { return (160 * 1024) / CF<KS, CH>::LDS_BYTES >= 2 ? 4 : 2; }
+
 template <int KS, int CH, bool MASK>
-__global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
+__global__ __launch_bounds__(kThreads, (conv32_min_blocks<KS, CH>())) void conv32_kernel(Conv32Params p) {
     using K = CF<KS, CH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
@@ -159,8 +164,15 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
         stage_load(k + 1);
         if (valid) {
             constexpr int NPT = K::NPT;
-            uint2 mk[NPT][2 * K::SPT];  // MASK: the mask values of this lane's rows, requested ahead of the k-loop
-            if constexpr (MASK) {
+            uint2 mk[NPT][2 * K::SPT];  // MASK: the mask values of this lane's rows
+            // Requested ahead of the k-loop where one workgroup runs per CU (nothing else covers their latency); behind it
+            // where two do and the 16 registers they would hold across the loop are what keeps the kernel above 128.
+#ifndef ISG_C32_MASK_EARLY
+            constexpr bool MASK_LATE = conv32_min_blocks<KS, CH>() == 4 && CH == 32;
+#else
+            constexpr bool MASK_LATE = false;
+#endif
+            auto load_mask = [&]() {
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt) {
                     const int cy = min(ty0 + NPT * wave + pt, p.H - 1), cx = min(tx0 + px_l, p.W - 1);
@@ -168,7 +180,8 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
 #pragma unroll
                     for (int g = 0; g < 2 * K::SPT; ++g) mk[pt][g] = *reinterpret_cast<const uint2*>(src + (8 * g + 4 * half) * 2);
                 }
-            }
+            };
+            if constexpr (MASK && !MASK_LATE) load_mask();
             f32x16 acc[NPT];
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(kThreads) void conv32_kernel(Conv32Params p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
+            if constexpr (MASK && MASK_LATE) load_mask();
             // epilogue: lane = pixel; its 16 accumulators are rows 8g + 4 half + i (g = reg >> 2, i = reg & 3).
             // The two halves swap two row groups so that each lane stores whole 16-byte runs of 8 channels.
 #pragma unroll
