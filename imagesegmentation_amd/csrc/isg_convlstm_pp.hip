@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kPPThreads) void conv3x3_pp_kernel(ConvParams p) {
                         }
                         const float g = act_tanh<true>(z[0]), ig = act_sigmoid<true>(z[1]);
                         const float fg = act_sigmoid<true>(z[2]), og = act_sigmoid<true>(z[3]);
-                        const float c = fg * cp[cl] + ig * g;
+                        const float c = __builtin_fmaf(fg, cp[cl], ig * g);  // (as lstm_pixel: one fused form)
                         cn[cl] = c;
                         hn[cl] = og * act_tanh<true>(c);
                         // kept for backward, 16 bytes per channel pair: the gate activations (j i f o | j i f o), or
@@ -978,8 +978,19 @@ int launch_conv_pp(const ConvParams& p, int mt, int mode, int num_cus, hipStream
 #else
         constexpr bool kEarly = false;
 #endif
-        if (p.c0 == 16 && p.c1 == 16) return launch_pp<16, 16, 2, 0, kEarly>(p, num_cus, stream);
-        if (p.c0 == 32 && p.c1 == 16) return launch_pp<32, 16, 2, 0, kEarly>(p, num_cus, stream);
+        // A launch whose 8-row tiles would leave half of the CUs without a workgroup (the reference's own 28 x 28 grid
+        // at a few dozen samples: one launch is then a fixed latency, not work) runs on 4-row tiles: twice the
+        // workgroups, each with half the pixels.  Same arithmetic per pixel, same results.
+        const int tiles8 = p.tiles_x * ((p.H + TH - 1) / TH) * p.B;
+#ifndef ISG_PP_NO_SMALL_TILES  // (switch for same-box A/B builds)
+        const bool small = tiles8 <= num_cus && p.pool_out == nullptr;
+#else
+        const bool small = false;
+#endif
+        if (p.c0 == 16 && p.c1 == 16)
+            return small ? launch_pp<16, 16, 2, 0, false, 1>(p, num_cus, stream) : launch_pp<16, 16, 2, 0, kEarly>(p, num_cus, stream);
+        if (p.c0 == 32 && p.c1 == 16)
+            return small ? launch_pp<32, 16, 2, 0, false, 1>(p, num_cus, stream) : launch_pp<32, 16, 2, 0, kEarly>(p, num_cus, stream);
         if (p.c0 == 48 && p.c1 == 16) return launch_pp<48, 16, 2, 0, false, 1>(p, num_cus, stream);
         return kNotSupported;
     }

@@ -182,7 +182,7 @@ __device__ __forceinline__ float act_tanh(float z) {
 #ifdef ISG_DIAG_NOACT
     if constexpr (FAST) return 0.5f * z;
 #endif
-    if constexpr (FAST) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008f * z) + 1.0f);
+    if constexpr (FAST) return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.88539008f * z) + 1.0f), 1.0f);
     else return 1.0f - 2.0f / (expf(2.0f * z) + 1.0f);
 }
 
@@ -195,8 +195,9 @@ __device__ __forceinline__ float act_tanh(float z) {
 // (ISG_SAVE_FACTORS), in the same 128 bytes per pixel: per channel pair A0 A1 B0 B1 f0 f1 o0 o1 (a 32-bit word
 // holds one value of both channels; the kernels finish channels in pairs).
 __device__ __forceinline__ void lstm_backward_factors(float g, float ig, float& a, float& b) {
-    a = ig * (1.0f - g * g);
-    b = g * (ig - ig * ig);
+    // (written as the fused operations they become, so that every instantiation rounds them the same way)
+    a = ig * __builtin_fmaf(-g, g, 1.0f);
+    b = g * __builtin_fmaf(-ig, ig, ig);
 }
 
 // c' = sig(f) c + sig(i) tanh(j);  h' = sig(o) tanh(c')   (reference convLSTM.py:40-43)
@@ -209,7 +210,7 @@ __device__ __forceinline__ void lstm_pixel(const float (&z)[32], const float (&c
         const float ig = act_sigmoid<FAST>(z[4 * cl + 1]);
         const float fg = act_sigmoid<FAST>(z[4 * cl + 2]);
         const float og = act_sigmoid<FAST>(z[4 * cl + 3]);
-        const float c = fg * cp[cl] + ig * g;
+        const float c = __builtin_fmaf(fg, cp[cl], ig * g);  // (one fused form in every instantiation)
         cn[cl] = c;
         hn[cl] = og * act_tanh<FAST>(c);
         gs[4 * cl] = g, gs[4 * cl + 1] = ig, gs[4 * cl + 2] = fg, gs[4 * cl + 3] = og;
