@@ -460,6 +460,63 @@ __global__ __launch_bounds__(256) void sum_slices_bias_kernel(const float* __res
 }
 }  // namespace
 
+namespace {
+constexpr int kColSumMaxBlocks = 256;
+
+// thread = column; a workgroup sums its share of the rows (every row read is 256 adjacent elements)
+template <typename T>
+__global__ __launch_bounds__(256) void column_sums_partial_kernel(const T* __restrict__ x, long long rows, int cols,
+                                                                  float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // (four loads in flight; summed in a fixed order)
+    long long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += ld(x, r * cols + c), s1 += ld(x, (r + 1) * cols + c);
+        s2 += ld(x, (r + 2) * cols + c), s3 += ld(x, (r + 3) * cols + c);
+    }
+    for (; r < r1; ++r) s0 += ld(x, r * cols + c);
+    partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void column_sums_finish_kernel(const float* __restrict__ partial, int nblk, int cols,
+                                                                 float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * cols + c];
+    out[c] = s;
+}
+}  // namespace
+
+extern "C" long long isg_column_sums_workspace_bytes(int cols) {
+    return cols >= 1 ? (long long)kColSumMaxBlocks * cols * (long long)sizeof(float) : -1;
+}
+
+extern "C" int isg_column_sums(const void* x, long long rows, int cols, int dtype, float* out, void* workspace,
+                               void* stream) {
+    int rc = check_rows("isg_column_sums", rows > 0x7fffffff ? 0x7fffffff : (int)rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    ISG_REQUIRE(out && workspace && (rows == 0 || x), ISG_EINVAL, "isg_column_sums: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    long long want = (rows + 31) / 32;
+    const int nblk = want < 1 ? 1 : (want > kColSumMaxBlocks ? kColSumMaxBlocks : (int)want);
+    const dim3 grid((cols + 255) / 256, nblk);
+    float* partial = static_cast<float*>(workspace);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(column_sums_partial_kernel<float>, grid, dim3(256), 0, s, static_cast<const float*>(x), rows,
+                           cols, partial);
+    else
+        hipLaunchKernelGGL(column_sums_partial_kernel<__hip_bfloat16>, grid, dim3(256), 0, s,
+                           static_cast<const __hip_bfloat16*>(x), rows, cols, partial);
+    rc = isg::check_launch("column_sums_partial_kernel");
+    if (rc != ISG_OK) return rc;
+    hipLaunchKernelGGL(column_sums_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nblk, cols, out);
+    return isg::check_launch("column_sums_finish_kernel");
+}
+
 extern "C" int isg_decode_begin(const int32_t* true_vertices, const int32_t* num_true, int B, int vmax, int hist, int T,
                                 int32_t* close_xy, int32_t* first_points, int32_t* history_points, int32_t* required,
                                 int32_t* durations, int32_t* predicted, void* stream) {

@@ -270,7 +270,7 @@ class _DenseHead(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         d_flat = dlogits @ wc.t() if ctx.needs_input_grad[0] else None
         dw = flat.t() @ dlogits
-        db = dlogits.sum(dim=0, dtype=torch.float32)
+        db = decode.column_sums(dlogits) if dlogits.is_cuda else dlogits.sum(dim=0, dtype=torch.float32)
         out = []
         for prm, g in ((w, dw), (b, db)):
             dst = ops.grad_destination(prm)

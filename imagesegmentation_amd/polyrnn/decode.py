@@ -192,6 +192,22 @@ def decode_polygons(predicted, durations, first_points, scale, prepend_history, 
     return vp, count
 
 
+def column_sums(x, out=None):
+    """isg_column_sums: float32 [cols] = sum over the rows of x [rows, cols] (float32 or bfloat16), a fixed order of
+    additions - the dense head's bias gradient over all (sample, step) rows (a library reduction over a tall matrix
+    takes 0.27 ms for 20,480 x 785, this 0.02).  ``out``: where to write (float32 [cols], contiguous)."""
+    rows, cols = x.shape
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty([cols], dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == cols
+    ws = torch.empty([_lib.lib().isg_column_sums_workspace_bytes(int(cols)) // 4], dtype=torch.float32, device=x.device)
+    rc = _lib.lib().isg_column_sums(_lib.ptr(x), int(rows), int(cols), dtype_code(x.dtype), _lib.ptr(out), _lib.ptr(ws),
+                                    _lib.current_stream())
+    _lib.check(rc, "isg_column_sums")
+    return out
+
+
 def dense_few_rows(flat, w, b, slices=None):
     """flat [M, K] @ w [K, N] + b in the operands' type for few rows against a long reduction axis (a decode or
     rollout step's head): one library GEMM has M N / tile output tiles for 256 CUs, so the reduction axis is cut

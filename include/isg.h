@@ -329,6 +329,13 @@ int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsign
                        unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
                        int32_t* out_xy, void* stream);
 
+/* out[c] = sum over rows of x[r][c] (float, overwritten; a fixed order of additions): the bias gradient of the dense
+ * head, tf.gradients of the bias add in reference polyrnn/History2LargeExperiment.py:48-50, whose rows are every
+ * (sample, step) of a batch - tens of thousands in a policy update.  x `dtype` [rows][cols];
+ * workspace: device scratch of isg_column_sums_workspace_bytes(cols) bytes. */
+long long isg_column_sums_workspace_bytes(int cols);
+int isg_column_sums(const void* x, long long rows, int cols, int dtype, float* out, void* workspace, void* stream);
+
 /* What the reference's decode loop starts from (polyrnn/Model.py:218-230), for every sample in one launch: with n =
  * num_true[r] and frame i of the first step showing true vertex (n - hist + i) mod n (create_history with end_idx =
  * len(v) - 1), first_points = history_points = those hist points, close_xy = frame 0's point (the closing vertex,

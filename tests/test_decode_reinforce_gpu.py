@@ -417,3 +417,19 @@ def test_head_at_a_handful_of_rows_equals_the_library_gemm():
     assert err <= max(err_one, 2.0 ** -8 * float(ref.abs().max()))
     assert decode.dense_few_rows(flat.float(), w.float(), b.float()) is None
     assert decode.dense_few_rows(flat[:, :1000].contiguous(), w[:1000].contiguous(), b) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(20480, 785), (320, 785), (1, 5), (37, 1024), (5000, 33)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_column_sums_against_float64(rows, cols, dtype):
+    """isg_column_sums (the dense head's bias gradient) against a float64 sum of the same values; two calls give the
+    same bits (a fixed order of additions)."""
+    from imagesegmentation_amd.polyrnn import decode
+    g = torch.Generator(device="cuda:0").manual_seed(rows + cols)
+    x = torch.randn([rows, cols], device="cuda:0", generator=g).to(dtype)
+    got = decode.column_sums(x)
+    ref = x.double().sum(0)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (cols,)
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(x.double().abs().sum(0).max()))
+    assert torch.equal(got, decode.column_sums(x))
