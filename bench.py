@@ -650,6 +650,46 @@ class GpuWorkload:
         out["kernels_per_vertex"] = getattr(model, "decode_launches_per_step", None)
         return out
 
+    def recurrence_leg(self):
+        """The recurrence of the EndTokenDeep_2 net alone at 224 x 224 (reference polyrnn/EndTokenDeepExperiment_2.py:
+        33-52: five ConvLSTM(16) layers, T = 10, two history frames), 32 sequences, forward + backward through
+        ``dynamic_rnn`` on synthetic features, every sequence at full length - the net's dense head cannot exist at
+        that size (50,177 x 802,816 weights), its recurrence can."""
+        from imagesegmentation_amd.convLSTM import ConvLSTMCell, MultiRNNCell, SequenceInput, dynamic_rnn
+        B, P, T, L, hist, C = 32, 224, 10, 5, 2, 16
+        dev, dt = self.device, self.dtype
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(90 + self.rank)
+        multi = MultiRNNCell([ConvLSTMCell([P, P], 16, [3, 3], compute_dtype=dt, device=dev) for _ in range(L)])
+        multi.build(C + hist, dev)
+        params = [q for c in multi.cells for q in (c.input_to_state_kernel, c.hidden_to_state_kernel, c.bias)]
+        feats = torch.randn([B, P, P, C], device=dev, generator=gen).to(dt).requires_grad_(True)
+        pts = torch.randint(0, P, [B, T, hist, 2], device=dev, generator=gen, dtype=torch.int32)
+        durations = torch.full([B], T, dtype=torch.int32, device=dev)
+        d_out = (torch.randn([B, T, P, P, 16], device=dev, generator=gen) * 0.1).to(dt)
+
+        def step():
+            for q in params + [feats]:
+                q.grad = None
+            out, _ = dynamic_rnn(multi, SequenceInput(static=feats, hist_points=pts), sequence_length=durations,
+                                 time_major=False, steps=T)
+            out.backward(d_out)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        n = 4
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / n
+        flops = 3.0 * T * P * P * sum(2 * 9 * ((C + hist if l == 0 else 16) + 16) * 64 for l in range(L))
+        return {"workload": "EndTokenDeep_2 recurrence alone, 224x224, %d sequences, T=%d, L=%d, hist=%d, fwd+bwd" %
+                            (B, T, L, hist), "ms_per_step": sec * 1e3, "sequences_per_s": B / sec,
+                "launches": 2 * T * L, "ms_per_cell_launch_pair": sec * 1e3 / (T * L),
+                "convlstm_gflop_per_sequence": flops / 1e9,
+                "convlstm_mfma_frac": flops * B / sec / 1e12 / MFMA_PEAK_TFLOPS["bf16" if dt == torch.bfloat16 else "f32"]}
+
     # -- legs with collectives (training steps / RL updates inside) --------------------------------------------
     def reinforce_leg(self):
         return bench_reinforce(self.share["rl_envs"], 3, self.device, self.rank, self.dtype)
@@ -798,6 +838,9 @@ class StubWorkload:
         return None
 
     def decode_leg(self):
+        return None
+
+    def recurrence_leg(self):
         return None
 
     def reinforce_leg(self):
@@ -950,6 +993,10 @@ def run_legs(args, world, rank, w):
         if rank == 0:
             note("extra leg: autoregressive decode latency")
             extra["decode"] = w.decode_leg()  # no collective
+            if args.config == "rnnconv" and args.dtype == "bf16":
+                note("extra leg: the five-layer recurrence of EndTokenDeep_2 alone at 224 x 224")
+                w.release()
+                extra["recurrence_224_L5"] = w.recurrence_leg()  # no collective
     comm.fence()  # nobody tears the process group down while another rank is still inside a leg
 
     return {
