@@ -73,15 +73,27 @@ def process_rollouts(rewards, values, lengths, gamma, lambda_=1.0, bootstrap=Non
     td = rewards + gamma * v_next - values
     r_in = rewards.clone()
     r_in[torch.arange(N, device=dev), last] += gamma * boot * (lengths > 0)
-    adv, ret = torch.zeros_like(td), torch.zeros_like(td)
-    acc_a = torch.zeros([N], dtype=torch.float64, device=dev)
-    acc_r = torch.zeros([N], dtype=torch.float64, device=dev)
-    for t in range(T - 1, -1, -1):
-        acc_a = torch.where(live[:, t], td[:, t] + gamma * lambda_ * acc_a, acc_a)
-        acc_r = torch.where(live[:, t], r_in[:, t] + gamma * acc_r, acc_r)
-        adv[:, t], ret[:, t] = acc_a, acc_r
+    # y[t] = x[t] + g y[t+1] is y = x @ M with M[s, t] = g^(s - t) for s >= t: the entries past a rollout's length
+    # are zero on input (they sit at the end, where the backward scan starts from zero), so one small float64
+    # product per quantity replaces T dependent steps of three launches each
+    adv = td @ _discount_matrix(T, gamma * lambda_, dev)
+    ret = r_in @ _discount_matrix(T, gamma, dev)
     zero = torch.zeros_like(adv)
     return torch.where(live, adv, zero), torch.where(live, ret, zero)
+
+
+_discount_matrices = {}
+
+
+def _discount_matrix(T, g, device):
+    """float64 [T, T]: M[s, t] = g^(s - t) for s >= t, else 0 (cached per length, factor and device)."""
+    key = (int(T), float(g), str(device))
+    m = _discount_matrices.get(key)
+    if m is None:
+        d = np.arange(T)[:, None] - np.arange(T)[None, :]
+        m = torch.tensor(np.where(d >= 0, float(g) ** np.maximum(d, 0), 0.0), dtype=torch.float64, device=device)
+        _discount_matrices[key] = m
+    return m
 
 
 def a3c_loss(logits, vf, actions, adv, r, live=None):
