@@ -258,6 +258,9 @@ class SequenceInput:
             self.C = cf + self.hist
         self._buf = None
         self._buf_t = None
+        #: a pass over this very input that has already run (``SequenceRecorder.record()``): the autograd node of
+        #: ``dynamic_rnn`` adopts it instead of running the forward launches again
+        self.recorded = None
 
     @property
     def scatter_hist(self):
@@ -321,73 +324,137 @@ def _zero_state(shape, dtype, device):
     return z
 
 
+class _SequencePass:
+    """The buffers of one pass over a sequence and the launches of one of its steps - shared by the whole-sequence
+    forward (``_run_sequence_forward``) and by a loop that advances step by step while it keeps everything a backward
+    sweep needs (``SequenceRecorder``)."""
+
+    def __init__(self, cells, seq, t_run, init_state, save, pool=1):
+        self.cells, self.seq, self.t_run, self.save, self.pool = cells, seq, t_run, save, pool
+        L, T = len(cells), seq.T
+        dt = cells[0].compute_dtype
+        B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
+        dev = seq.device
+        self.packed = packed = [seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
+        seq.prepare(dt, packed[0].cs)
+        # Per layer a list of state tensors: entry 0 is the initial state, entry k the state after step k - 1 when
+        # everything is kept for backward, else entries 1 and 2 alternate.  None = zero state: ONE zero tensor per
+        # shape, kept for the life of the process and only ever read - neither a fill nor a copy per sequence.
+        n_buf = T if save else 2
+        self.Hs, self.Cs = [], []
+        # a layer that starts from the zero state: its first step is told so and reads no state at all
+        # (ISG_NO_ZERO_STATE=1: the shared zero tensors are read like any state, for A/B runs)
+        self.from_zero = [init_state[l][0] is None and init_state[l][1] is None and
+                          not os.environ.get("ISG_NO_ZERO_STATE") for l in range(L)]
+        # What a layer keeps for backward (next to its states): the backward factors where the fused backward step
+        # exists for its shape, else the gate activations for the three-kernel backward.
+        # (Layer 0's input gradient has the width of the static features when the input is the tiled form: the fused
+        # step writes it in runs of 8 channels, other widths take the three-kernel backward.)
+        dx0 = seq.static.shape[-1] if seq.x_seq is None else None
+        self.layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W, dx0 if l == 0 else None)
+                        else ops.SAVE_GATES for l in range(L)]
+        cdts = [_state_dtype(packed[l], B, H, W, dx0 if l == 0 else None) for l in range(L)]
+        for l in range(L):
+            c0, h0 = init_state[l]
+            c_init = _zero_state([B, H, W, F], cdts[l], dev) if c0 is None else c0.detach().to(cdts[l]).contiguous()
+            h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
+            self.Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
+            self.Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=cdts[l], device=dev).unbind(0)))
+        self.Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, self.layouts[l]), dtype=dt, device=dev)
+                   for l in range(L)] if save else None
+        # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
+        self.fused_pool = pool > 1 and ops.pooled_fwd_supported(packed[L - 1], B, H, W, pool)
+        self.oh, self.ow = (H // pool, W // pool) if self.fused_pool else (H, W)
+        self.out = torch.empty([B, T, self.oh, self.ow, F], dtype=dt, device=dev)
+        if t_run < T:
+            self.out[:, t_run:].zero_()
+        self.cur = 0
+
+    def step(self, t, durations_dev, t_mask=None):
+        """The launches of step t.  ``t_mask``: the step index the per-sample lengths are compared with (default t)."""
+        cells, seq, save = self.cells, self.seq, self.save
+        L, T = len(cells), seq.T
+        H, W, F = seq.H, seq.W, cells[0]._filters
+        x = seq.get(t)
+        cur = self.cur
+        nxt = cur + 1 if save else (2 if cur == 1 else 1)
+        for l in range(L):
+            top = l == L - 1
+            first = t == 0 and self.from_zero[l]
+            ops.set_layer(l, ",zs" if first else "")
+            ops.cell_fwd(x, None if first else self.Hs[l][cur], None if first else self.Cs[l][cur], self.packed[l],
+                         durations_dev, t if t_mask is None else t_mask,
+                         out=self.out[:, t] if top and not self.fused_pool else None, out_batch_stride=T * H * W * F,
+                         save_gates=False, h_out=self.Hs[l][nxt], c_out=self.Cs[l][nxt],
+                         gates=self.Gs[l][t] if save else None, save_layout=self.layouts[l],
+                         hist_points=seq.points(t) if l == 0 else None,
+                         pool_out=self.out[:, t] if top and self.fused_pool else None,
+                         pool_batch_stride=T * self.oh * self.ow * F, pool=self.pool)
+            x = self.Hs[l][nxt]
+        self.cur = nxt
+        ops.set_layer(0)
+
+    def result(self, init_state):
+        L = len(self.cells)
+        out = self.out
+        if self.pool > 1 and not self.fused_pool:
+            out = ops.avgpool(out, self.pool)
+        cur, Hs, Cs = self.cur, self.Hs, self.Cs
+        if cur == 0:  # no step ran: hand out copies, never the shared zero tensors or the caller's own state
+            # (of the state as it was given, where one was: not of its copy in the kernels' storage type)
+            final = [(Cs[l][0].clone() if init_state[l][0] is None else init_state[l][0].detach().clone(),
+                      Hs[l][0].clone() if init_state[l][1] is None else init_state[l][1].detach().clone())
+                     for l in range(L)]
+        else:
+            final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
+        return out, final, (Hs, Cs, self.Gs, self.packed, self.layouts)
+
+
 def _run_sequence_forward(cells, seq, durations_dev, t_run, init_state, save, pool=1):
     """Shared by the autograd function and the no-grad decode path.  ``pool`` = k > 1: the returned outputs
     are the k x k window means, [B, T, H/k, W/k, F] - written by the top layer's kernel itself where it can,
     by a pooling pass over the full-resolution outputs otherwise."""
-    L, T = len(cells), seq.T
-    dt = cells[0].compute_dtype
-    B, H, W, F = seq.B, seq.H, seq.W, cells[0]._filters
-    dev = seq.device
-    packed = [seq.layer0_packed(cells[0])] + [c.packed() for c in cells[1:]]
-    seq.prepare(dt, packed[0].cs)
-    # Per layer a list of state tensors: entry 0 is the initial state, entry k the state after step k - 1 when
-    # everything is kept for backward, else entries 1 and 2 alternate.  None = zero state: ONE zero tensor per
-    # shape, kept for the life of the process and only ever read - neither a fill nor a copy per sequence.
-    n_buf = T if save else 2
-    Hs, Cs = [], []
-    # a layer that starts from the zero state: its first step is told so and reads no state at all
-    # (ISG_NO_ZERO_STATE=1: the shared zero tensors are read like any state, for A/B runs)
-    from_zero = [init_state[l][0] is None and init_state[l][1] is None and not os.environ.get("ISG_NO_ZERO_STATE")
-                 for l in range(L)]
-    # What a layer keeps for backward (next to its states): the backward factors where the fused backward step
-    # exists for its shape, else the gate activations for the three-kernel backward.
-    # (Layer 0's input gradient has the width of the static features when the input is the tiled form: the fused
-    # step writes it in runs of 8 channels, other widths take the three-kernel backward.)
-    dx0 = seq.static.shape[-1] if seq.x_seq is None else None
-    layouts = [ops.SAVE_FACTORS if ops.bwd_fused_supported(packed[l], B, H, W, dx0 if l == 0 else None)
-               else ops.SAVE_GATES for l in range(L)]
-    cdts = [_state_dtype(packed[l], B, H, W, dx0 if l == 0 else None) for l in range(L)]
-    for l in range(L):
-        c0, h0 = init_state[l]
-        c_init = _zero_state([B, H, W, F], cdts[l], dev) if c0 is None else c0.detach().to(cdts[l]).contiguous()
-        h_init = _zero_state([B, H, W, F], dt, dev) if h0 is None else h0.detach().to(dt).contiguous()
-        Hs.append([h_init] + list(torch.empty([n_buf, B, H, W, F], dtype=dt, device=dev).unbind(0)))
-        Cs.append([c_init] + list(torch.empty([n_buf, B, H, W, F], dtype=cdts[l], device=dev).unbind(0)))
-    Gs = [torch.empty([T] + ops.saved_shape(B, H, W, F, layouts[l]), dtype=dt, device=dev) for l in range(L)] \
-        if save else None
-    # every step that runs writes its whole slice (zeros for finished samples); only the tail needs clearing
-    fused_pool = pool > 1 and ops.pooled_fwd_supported(packed[L - 1], B, H, W, pool)
-    oh, ow = (H // pool, W // pool) if fused_pool else (H, W)
-    out = torch.empty([B, T, oh, ow, F], dtype=dt, device=dev)
-    if t_run < T:
-        out[:, t_run:].zero_()
-    cur = 0
+    run = _SequencePass(cells, seq, t_run, init_state, save, pool)
     for t in range(t_run):
-        x = seq.get(t)
-        nxt = cur + 1 if save else (2 if cur == 1 else 1)
-        for l in range(L):
-            top = l == L - 1
-            first = t == 0 and from_zero[l]
-            ops.set_layer(l, ",zs" if first else "")
-            ops.cell_fwd(x, None if first else Hs[l][cur], None if first else Cs[l][cur], packed[l], durations_dev, t,
-                         out=out[:, t] if top and not fused_pool else None, out_batch_stride=T * H * W * F,
-                         save_gates=False, h_out=Hs[l][nxt], c_out=Cs[l][nxt], gates=Gs[l][t] if save else None,
-                         save_layout=layouts[l], hist_points=seq.points(t) if l == 0 else None,
-                         pool_out=out[:, t] if top and fused_pool else None, pool_batch_stride=T * oh * ow * F,
-                         pool=pool)
-            x = Hs[l][nxt]
-        cur = nxt
-    ops.set_layer(0)
-    if pool > 1 and not fused_pool:
-        out = ops.avgpool(out, pool)
-    if cur == 0:  # no step ran: hand out copies, never the shared zero tensors or the caller's own state
-        # (of the state as it was given, where one was: not of its copy in the kernels' storage type)
-        final = [(Cs[l][0].clone() if init_state[l][0] is None else init_state[l][0].detach().clone(),
-                  Hs[l][0].clone() if init_state[l][1] is None else init_state[l][1].detach().clone()) for l in range(L)]
-    else:
-        final = [(Cs[l][cur], Hs[l][cur]) for l in range(L)]
-    return out, final, (Hs, Cs, Gs, packed, layouts)
+        run.step(t, durations_dev)
+    return run.result(init_state)
+
+
+class SequenceRecorder:
+    """A rollout's recurrence advanced one step at a time from the zero state - each step's history points are only
+    known once the previous step's action has been taken - that keeps what the backward sweep of ``dynamic_rnn``
+    reads (states, backward factors, outputs of every step).  ``SequenceInput.recorded = recorder.record()`` on the
+    sequence input of the update's ``dynamic_rnn`` then makes that node adopt the pass instead of running it again:
+    the same launches on the same inputs would write the same numbers (reference
+    polyrl/ReinforceOverfitExperiment.py:147-176 runs the network a second time for the update).  Every sample runs
+    every step here (a finished episode's later steps are ignored by the update's per-sample lengths: its backward
+    sweep skips them and their outputs meet zero weights in the loss)."""
+
+    def __init__(self, multi, static, hist, steps):
+        cells = list(multi.cells) if isinstance(multi, MultiRNNCell) else [multi]
+        B = static.shape[0]
+        (multi if isinstance(multi, MultiRNNCell) else MultiRNNCell(cells)).build(static.shape[-1] + hist, static.device)
+        self.hist_points = torch.full([B, steps, hist, 2], -1, dtype=torch.int32, device=static.device)
+        self.seq = SequenceInput(static=static, hist_points=self.hist_points)
+        self.init_state = [(None, None)] * len(cells)
+        self.run = _SequencePass(cells, self.seq, steps, self.init_state, True)
+        self.t = 0
+
+    def step(self, hist_points=None):
+        """Advances every layer once with this step's history points (int32 [B, hist, 2]).  Returns the top layer's
+        output of the step, [B, 1, H, W, F] (a view of the kept outputs)."""
+        t = self.t
+        if self.seq.hist > 0:
+            self.seq.hist_points[:, t] = hist_points
+        self.run.step(t, None)
+        self.t = t + 1
+        return self.run.out[:, t:t + 1]
+
+    def record(self):
+        """What ``SequenceInput.recorded`` takes; the recorder must have run all of its steps."""
+        if self.t != self.seq.T:
+            raise RuntimeError("the recorder ran %d of its %d steps" % (self.t, self.seq.T))
+        return self.run.result(self.init_state)
 
 
 class RecurrentStepper:
@@ -526,8 +593,16 @@ class _SequenceFunction(torch.autograd.Function):
         cells = list(multi.cells)
         L = len(cells)
         init_state = [(tensors[1 + 2 * l], tensors[2 + 2 * l]) for l in range(L)]
-        out, final, (Hs, Cs, Gs, packed, layouts) = _run_sequence_forward(cells, seq, durations_dev, t_run, init_state,
-                                                                          True, pool)
+        recorded = getattr(seq, "recorded", None)
+        if recorded is not None:
+            # a pass over the same inputs with the same weights that already ran step by step (SequenceRecorder)
+            if pool != 1 or any(c is not None or h is not None for c, h in init_state) or t_run != seq.T:
+                raise NotImplementedError("a recorded pass: zero initial state, no pooled output, all steps run")
+            out, final, (Hs, Cs, Gs, packed, layouts) = recorded
+            seq.prepare(cells[0].compute_dtype, packed[0].cs)
+        else:
+            out, final, (Hs, Cs, Gs, packed, layouts) = _run_sequence_forward(cells, seq, durations_dev, t_run,
+                                                                              init_state, True, pool)
         ctx.multi, ctx.seq, ctx.durations_dev, ctx.t_run = multi, seq, durations_dev, t_run
         ctx.saved = (Hs, Cs, Gs, packed, layouts)
         ctx.in_dtype = tensors[0].dtype

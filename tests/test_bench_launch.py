@@ -37,7 +37,8 @@ def test_every_leg_ran_and_the_line_carries_the_exchange_facts():
     rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 128 and rec["config"]["parallelism"] == "dp2"
     assert rec["allreduce_bytes"] > 0
-    assert set(rec["extra_runs"]) == {"all_durations_T", "fresh_batches", "f32", "endtokendeep2", "decode"}
+    assert set(rec["extra_runs"]) == {"all_durations_T", "fresh_batches", "f32", "endtokendeep2", "decode",
+                                      "recurrence_224_L5"}
     assert rec["iou"]["rollouts"] == 2 * 16384 and rec["reinforce"]["envs"] == 2 * 2048 and rec["a3c"]["envs"] == 2 * 1024
     # MAX over ranks of the stand-in legs' times (rank r reports 1 + r ms)
     assert rec["iou"]["ms_per_launch"] == 2.0 and rec["reinforce"]["ms_per_step"] == 2.0
