@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import parallel
-from ..convLSTM import LSTMStateTuple, RecurrentStepper, SequenceInput, _run_sequence_forward
+from ..convLSTM import LSTMStateTuple, RecurrentStepper, SequenceInput, SequenceRecorder, _run_sequence_forward
 from ..polyrnn import decode
 from ..polyrnn.Model import Model
 from .batched_env import BatchedPolygonEnv, DevicePolygonPool
@@ -98,9 +98,9 @@ class ExperimentPolicyEstimator(Model):
         return action, state
 
     # -- learning ----------------------------------------------------------------------------------
-    def policy_loss(self, images, durations, histories, actions, td_targets):
-        """mean over [B, T] of xent(action) * td (reference :45-48)."""
-        logits, _ = self.forward(images, durations, histories)
+    def policy_loss(self, images, durations, histories, actions, td_targets, recorded=None):
+        """mean over [B, T] of xent(action) * td (reference :45-48).  ``recorded``: see ``Model.forward``."""
+        logits, _ = self.forward(images, durations, histories, recorded=recorded)
         actions = self._to_dev(actions, torch.int64)
         dense = actions[..., 0] * self.action_size + actions[..., 1]
         td = self._to_dev(td_targets, torch.float32)
@@ -257,14 +257,21 @@ class BatchedReinforce:
                                      device=policy.device, state_dtype=torch.float32)
         self.num_envs = num_envs
         self.gamma = gamma
+        import os
+        dt_ok = policy.compute_dtype == torch.bfloat16 and policy.device.type == "cuda"
+        #: the update adopts the rollout's forward pass of the recurrence (bf16 on the GPU: both passes then run the
+        #: same kernels on the same inputs; elsewhere the update runs its own)
+        self.reuse_forward = dt_ok and not os.environ.get("ISG_NO_FORWARD_REUSE")
         self.pool = None
         if device_pool:
             self.pool = DevicePolygonPool(dataset, policy.device, dtype=torch.float32,
                                           vcap=policy.history_length + policy.max_timesteps + 1, seed=pool_seed)
 
-    def rollout(self, images=None, polygons=None):
+    def rollout(self, images=None, polygons=None, keep_forward=False):
         """Runs every environment for up to max_timesteps sampled actions.  Returns a dict with the
-        recorded episode (history points, actions, lengths), rewards (float64 [N]) and counts."""
+        recorded episode (history points, actions, lengths), rewards (float64 [N]) and counts.
+        ``keep_forward``: the recurrence keeps what its backward sweep reads (``SequenceRecorder``), so that the
+        update of these episodes does not run the same forward steps a second time (entry "forward")."""
         pol, env = self.policy, self.env
         N, T, hist = self.num_envs, pol.max_timesteps, pol.history_length
         if images is None and self.pool is not None:
@@ -277,7 +284,8 @@ class BatchedReinforce:
         lengths = torch.zeros([N], dtype=torch.int32, device=dev)
         with torch.no_grad():
             features = pol.encode(env.image)
-            stepper = RecurrentStepper(pol.rnn, features, hist)
+            stepper = SequenceRecorder(pol.rnn, features, hist, T) if keep_forward else \
+                RecurrentStepper(pol.rnn, features, hist)
             for t in range(T):
                 logits = pol.head(stepper.step(env.history_points))[:, 0]
                 a = pol.sample_actions(logits)
@@ -287,7 +295,7 @@ class BatchedReinforce:
             # an episode that never terminated earns nothing (the scalar loop ends it with reward 0)
             reward = torch.where(env.done, reward, torch.zeros_like(reward))
         return dict(images=env.image, points=points, actions=actions, lengths=lengths, reward=reward, inter=inter,
-                    union=union, done=env.done.clone())
+                    union=union, done=env.done.clone(), forward=stepper.record() if keep_forward else None)
 
     def returns(self, ep):
         """Discounted return per step: the only non-zero reward is the terminal one, so
@@ -304,13 +312,17 @@ class BatchedReinforce:
         pol = self.policy
         pol._flat_grad.zero_()
         td = self.returns(ep)
-        loss = pol.policy_loss(ep["images"], ep["lengths"], ep["points"], ep["actions"], td) * self.num_envs
+        loss = pol.policy_loss(ep["images"], ep["lengths"], ep["points"], ep["actions"], td,
+                               recorded=ep.get("forward")) * self.num_envs
+        ep["forward"] = None  # (its buffers belong to the update's backward sweep, which releases them)
         loss.backward()
         pol.gradBuffer += pol._flat_grad
         pol.apply_accumulated()
         return loss.detach() / self.num_envs
 
     def step(self, images=None, polygons=None):
-        ep = self.rollout(images, polygons)
+        # (the weights do not change between a step's rollout and its update: the update adopts the rollout's
+        # forward pass; ISG_NO_FORWARD_REUSE=1 runs it again, for A/B runs)
+        ep = self.rollout(images, polygons, keep_forward=self.reuse_forward)
         loss = self.update(ep)
         return ep, loss

@@ -573,9 +573,13 @@ class Model:
             logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)
 
-    def forward(self, images, durations, histories, initial_state=None, steps=None):
+    def forward(self, images, durations, histories, initial_state=None, steps=None, recorded=None):
+        """``recorded``: a pass of the recurrence over these very inputs with the present weights that has already
+        run (``convLSTM.SequenceRecorder.record()`` of a rollout); the recurrence's node adopts it instead of
+        launching the forward steps again."""
         features = self.encode(images)
         seq = self._sequence_input(features, histories)
+        seq.recorded = recorded
         # durations already on the device (a batch from data.DeviceBatchBuilder) are not fetched back: all
         # max_timesteps steps (or ``steps``, a bound the caller knows) run under the per-sample mask
         if steps is None:

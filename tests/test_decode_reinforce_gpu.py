@@ -433,3 +433,34 @@ def test_column_sums_against_float64(rows, cols, dtype):
     assert got.dtype == torch.float32 and tuple(got.shape) == (cols,)
     assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(x.double().abs().sum(0).max()))
     assert torch.equal(got, decode.column_sums(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("end_token", [False, True])
+def test_update_that_adopts_the_rollouts_forward_pass_equals_the_update_that_runs_its_own(end_token):
+    """BatchedReinforce.step with the recurrence of the rollout kept for the update (SequenceRecorder) against the
+    update that runs the forward steps a second time (ISG_NO_FORWARD_REUSE): same episodes, and after two steps
+    the same weights bit for bit - the adopted pass holds the numbers the second pass would compute, and what it
+    holds beyond an episode's end never reaches a gradient."""
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl.reinforce import BatchedReinforce, ExperimentPolicyEstimator
+    P, T, N = 28, 10, 64
+    ds = data.PolygonDataset.synthetic(32, P, P, T, 2, seed=5, shape_mask_fn=oracle_raster.create_shape_mask)
+    runs = []
+    for reuse in (True, False):
+        pol = ExperimentPolicyEstimator(P, P, max_timesteps=T, end_token=end_token, compute_dtype=torch.bfloat16,
+                                        device=DEV, sample_seed=11, seed=3)
+        with torch.no_grad():
+            pol.dense_bias[-1 if end_token else 0] += 4.0  # (episodes of different lengths, some ended early)
+        br = BatchedReinforce(pol, ds, N, device_pool=True, pool_seed=8)
+        assert br.reuse_forward
+        br.reuse_forward = reuse
+        eps = [br.step()[0] for _ in range(2)]
+        runs.append((eps, [p.detach().clone() for p in pol.trainable_variables]))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for key in ("actions", "lengths", "reward", "points"):
+            assert torch.equal(a[key], b[key]), key
+    if end_token:  # (the biased end-token class ends episodes early: steps beyond an episode's end are in the pass)
+        assert 0 < int(runs[0][0][0]["lengths"].min()) < T
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
