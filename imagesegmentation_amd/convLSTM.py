@@ -583,6 +583,65 @@ class WideStepper:
         return self.out
 
 
+class WideRecorder:
+    """``WideStepper`` for a rollout whose update follows under the same weights: the cell is advanced one step at a
+    time from the zero state and everything the backward sweep of ``dynamic_rnn`` reads is kept (joint inputs, states
+    and backward factors of every step and group, the joint outputs), in buffers that stay where they are - a
+    captured graph may replay the loop.  ``SequenceInput.recorded = recorder.record()`` on the input of the update's
+    ``dynamic_rnn`` makes that node adopt the pass instead of launching the same steps on the same inputs again."""
+
+    def __init__(self, cell, batch, device, steps):
+        self.cell, self.T = cell, int(steps)
+        Fh, F, dt = ops.F_HIDDEN, cell._filters, cell.compute_dtype
+        H, W = cell._shape
+        T, B = self.T, batch
+        self.k = k = F // Fh
+        self.C = C = int(cell.input_to_state_kernel.shape[2])
+        self.groups = _wide_groups(cell, C)
+        cs = self.groups[0][1].cs
+        self.layout = ops.SAVE_FACTORS if ops.bwd_fused_supported(self.groups[0][1], B, H, W) else ops.SAVE_GATES
+        self.xw = torch.zeros([T, B, H, W, cs], dtype=dt, device=device)
+        self.Hs = [[torch.zeros([B, H, W, Fh], dtype=dt, device=device)] +
+                   list(torch.empty([T, B, H, W, Fh], dtype=dt, device=device).unbind(0)) for _ in range(k)]
+        self.Cs = [[torch.zeros([B, H, W, Fh], dtype=torch.float32, device=device)] +
+                   list(torch.empty([T, B, H, W, Fh], dtype=torch.float32, device=device).unbind(0)) for _ in range(k)]
+        self.Gs = [torch.empty([T] + ops.saved_shape(B, H, W, Fh, self.layout), dtype=dt, device=device)
+                   for _ in range(k)]
+        self.out = torch.empty([B, T, H, W, F], dtype=dt, device=device)
+        self.step_out = torch.empty([B, H, W, F], dtype=dt, device=device)
+        self.t = 0
+
+    def reset(self):
+        """Back to the first step of the zero state (nothing to clear: every step rewrites its slots, and the slots of
+        the zero state are never written)."""
+        self.t = 0
+
+    def step(self, x):
+        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step (a buffer the next step overwrites)."""
+        Fh, C, F, t, T = ops.F_HIDDEN, self.C, self.cell._filters, self.t, self.T
+        if t >= T:
+            raise RuntimeError("the recorder holds %d steps" % T)
+        groups = _wide_groups(self.cell, C)
+        xw = self.xw[t]
+        _, H, W, _ = xw.shape
+        ops.copy_slice(xw[..., :C], x if x.dtype == xw.dtype else x.to(xw.dtype))
+        for s in range(1, self.k):
+            ops.copy_slice(xw[..., C + Fh * (s - 1):C + Fh * s], self.Hs[s][t])
+        for s in range(self.k):
+            ops.cell_fwd(xw, self.Hs[0][t], self.Cs[s][t], groups[s][1], None, t,
+                         out=self.out[:, t, ..., Fh * s:Fh * s + Fh], out_batch_stride=T * H * W * F, out_pixel_stride=F,
+                         save_gates=False, h_out=self.Hs[s][t + 1], c_out=self.Cs[s][t + 1], gates=self.Gs[s][t],
+                         save_layout=self.layout)
+        self.t = t + 1
+        return ops.copy_slice(self.step_out, self.out[:, t])
+
+    def record(self):
+        """What ``SequenceInput.recorded`` takes once all steps have run."""
+        if self.t != self.T:
+            raise RuntimeError("the recorder ran %d of its %d steps" % (self.t, self.T))
+        return (self.xw, self.Hs, self.Cs, self.Gs, _wide_groups(self.cell, self.C), self.layout, self.out)
+
+
 class _SequenceFunction(torch.autograd.Function):
     """MultiRNNCell + dynamic_rnn as ONE autograd node: T*L fused cell launches forward, and the
     hand-written reverse sweep (pointwise, weight-gradient and data-gradient kernels) backward."""
@@ -798,10 +857,23 @@ class _WideSequenceFunction(torch.autograd.Function):
     The state is kept per group ([B, H, W, 16] each) so that nothing is sliced or re-packed inside the loops."""
 
     @staticmethod
-    def forward(ctx, cell, durations_dev, t_run, x_seq, c0, h0, w_x, w_h, bias):
+    def forward(ctx, cell, durations_dev, t_run, x_seq, c0, h0, w_x, w_h, bias, recorded=None):
         T, B, H, W, C = x_seq.shape
         Fh, F, dt, dev = ops.F_HIDDEN, cell._filters, cell.compute_dtype, x_seq.device
         k = F // Fh
+        if recorded is not None:
+            # a pass over the same inputs from the zero state with the same weights that already ran step by step
+            # (WideRecorder): adopted as it is
+            if durations_dev is not None or t_run != T:
+                raise NotImplementedError("a recorded pass: all steps of every sample")
+            xw, Hs, Cs, Gs, groups, layout, out = recorded
+            ctx.cell, ctx.durations_dev, ctx.t_run, ctx.C = cell, None, t_run, C
+            ctx.saved = (xw, Hs, Cs, Gs, groups, layout)
+            ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
+            ctx.batch_major = T > 1 and B > 1 and x_seq.transpose(0, 1).is_contiguous()
+            ctx.set_materialize_grads(False)
+            return out, torch.cat([Cs[s][t_run] for s in range(k)], dim=-1), \
+                torch.cat([Hs[s][t_run] for s in range(k)], dim=-1)
         groups = _wide_groups(cell, C)
         cs = groups[0][1].cs
         keep = not getattr(ctx, "forward_only", False)  # without a backward pass no gates are stored
@@ -947,7 +1019,7 @@ class _WideSequenceFunction(torch.autograd.Function):
         else:
             d_x = ops.copy_slice(torch.empty([T, B, H, W, C], dtype=dt, device=dev), d_xw[..., :C])
         return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
-                dw_x, dw_h, dbias)
+                dw_x, dw_h, dbias, None)
 
 
 def _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state):
@@ -959,7 +1031,7 @@ def _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state):
     cell = multi.cells[0]
     c0, h0 = initial_state[0]
     args = (cell, durations_dev, t_run, seq.x_seq, c0, h0, cell.input_to_state_kernel, cell.hidden_to_state_kernel,
-            cell.bias)
+            cell.bias, getattr(seq, "recorded", None))
     if torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in args):
         out, c, h = _WideSequenceFunction.apply(*args)
     else:

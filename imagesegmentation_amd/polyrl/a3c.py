@@ -28,7 +28,8 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel
-from ..convLSTM import ConvLSTMCell, LSTMStateTuple, WideStepper, dynamic_rnn, glorot_uniform_
+from ..convLSTM import (ConvLSTMCell, LSTMStateTuple, SequenceInput, WideRecorder, WideStepper, dynamic_rnn,
+                        glorot_uniform_)
 from ..optim import FlatAdam
 from ..polyrnn import decode
 from ..polyrnn.Model import _DenseHead, _EncoderChain, _head_weights, conv2d_same_relu, encoder_chain_supported
@@ -217,11 +218,15 @@ class LSTMPolicy:
             y = conv2d_same_relu(y, w, b, dt)
         return y.contiguous()
 
-    def forward(self, x, state):
-        """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out."""
+    def forward(self, x, state, recorded=None):
+        """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out.
+        ``recorded``: the recurrence's pass over these very observations from the zero state with the present weights
+        (``WideRecorder.record()`` of the rollout that produced them); the recurrence's node adopts it."""
         N, T = x.shape[0], x.shape[1]
         feats = self._encode(x.reshape((N * T,) + tuple(x.shape[2:]))).reshape((N, T) + tuple(x.shape[2:4]) + (32,))
-        out, final = dynamic_rnn(self.lstm, feats, initial_state=LSTMStateTuple(*state), time_major=False)
+        seq = SequenceInput(x_seq=feats.transpose(0, 1))
+        seq.recorded = recorded
+        out, final = dynamic_rnn(self.lstm, seq, initial_state=LSTMStateTuple(*state), time_major=False)
         logits, vf = self._heads(out.reshape(N * T, -1))
         return logits.reshape(N, T, -1), vf.reshape(N, T), final
 
@@ -254,6 +259,10 @@ class LSTMPolicy:
         """Recurrent state of ``num_envs`` environments for ``act_step``: kept on the device in the layout the cell
         kernels use, from the zero state (reference polyrl/a3c/model.py:27-29)."""
         return WideStepper(self.lstm, num_envs, self.device)
+
+    def recorder(self, num_envs, steps):
+        """``stepper`` that also keeps the recurrence's pass for the update (``WideRecorder``)."""
+        return WideRecorder(self.lstm, num_envs, self.device, steps)
 
     def act_step(self, ob, stepper):
         """``act`` with the recurrent state held by ``stepper`` (advanced in place): (action index int64 [N],
@@ -308,6 +317,11 @@ class A3C:
         #: microseconds each: the host cannot issue them as fast as the GPU retires them)
         self.rollout_graph = self.opt.flat_param.is_cuda and not os.environ.get("ISG_NO_ROLLOUT_GRAPH")
         self._rollout = None
+        #: the update adopts the rollout's pass of the recurrence instead of running it again (the stepper path: a
+        #: 32-filter cell on the GPU in bf16; ISG_NO_FORWARD_REUSE=1 for A/B runs)
+        self.reuse_forward = (self.opt.flat_param.is_cuda and self.local_network.filters > 16 and
+                              self.local_network.compute_dtype == torch.bfloat16 and
+                              not os.environ.get("ISG_NO_FORWARD_REUSE"))
 
     def pull_batch(self, images=None, polygons=None):
         """Every environment from reset to its terminal step or the step limit."""
@@ -349,7 +363,7 @@ class A3C:
         where = tuple(t.data_ptr() for t in tensors) + (N, T, P)
         if r is None or r["where"] != where:
             r = self._rollout = dict(
-                where=where, graph=None, rec=pi.stepper(N), offset=torch.zeros([], dtype=torch.int64, device=dev),
+                where=where, graph=None, rec=pi.recorder(N, T) if self.reuse_forward else pi.stepper(N), offset=torch.zeros([], dtype=torch.int64, device=dev),
                 obs=torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev),
                 xy=torch.zeros([N, T, 2], dtype=torch.int32, device=dev),
                 actions=torch.zeros([N, T], dtype=torch.int64, device=dev),
@@ -401,7 +415,7 @@ class A3C:
             body()
             r["warm"] = True
         return dict(si=r["obs"], a=r["actions"], values=r["values"], rewards=r["rewards"], lengths=r["lengths"],
-                    terminal=env.done.clone())
+                    terminal=env.done.clone(), forward=r["rec"].record() if self.reuse_forward else None)
 
     def process(self, images=None, polygons=None):
         with self.derived:
@@ -417,7 +431,8 @@ class A3C:
         adv, r = process_rollouts(batch["rewards"], batch["values"], batch["lengths"], self.gamma, self.lambda_)
         live = torch.arange(T, device=adv.device)[None, :] < batch["lengths"][:, None]
         self.opt.zero_grad()
-        logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N))
+        # (the weights have not changed since the rollout: the update adopts its pass of the recurrence)
+        logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N), recorded=batch.get("forward"))
         loss, parts = a3c_loss(logits.reshape(N * T, -1), vf.reshape(-1), batch["a"].reshape(-1), adv.reshape(-1),
                                r.reshape(-1), live.reshape(-1))
         (loss / N).backward()

@@ -269,7 +269,13 @@ class _DenseHead(torch.autograd.Function):
         w, b = ctx.params
         dlogits = dlogits.contiguous()
         d_flat = dlogits @ wc.t() if ctx.needs_input_grad[0] else None
-        dw = flat.t() @ dlogits
+        if dlogits.shape[1] < 8 and dlogits.is_cuda:
+            # a head of a few columns (the actor-critic value head has one): as [K, R] x [R, 1] the library takes a
+            # matrix-vector path that holds the launching thread for 12 ms per call at R = 10,240, K = 32,768; the
+            # transposed product is an ordinary GEMM (0.02 ms of host time, 0.14 ms instead of 0.58 on the device)
+            dw = (dlogits.t() @ flat).t()
+        else:
+            dw = flat.t() @ dlogits
         db = decode.column_sums(dlogits) if dlogits.is_cuda else dlogits.sum(dim=0, dtype=torch.float32)
         out = []
         for prm, g in ((w, dw), (b, db)):

@@ -192,3 +192,37 @@ def test_rollout_replayed_as_a_graph_equals_the_rollout_launched_step_by_step(mo
     assert torch.equal(runs[False][1], runs[True][1])
     # successive rollouts draw different actions (the stream position lives on the device and moves with each step)
     assert not torch.equal(runs[True][0][2]["a"], runs[True][0][3]["a"])
+
+
+@pytest.mark.gpu
+def test_update_that_adopts_the_rollouts_recurrence_equals_the_update_that_runs_its_own():
+    """A3C.reuse_forward: the rollout keeps its pass of the 32-filter recurrence (WideRecorder, also inside the
+    replayed graph) and the update's backward sweep reads it, against the update that runs the forward steps again:
+    the same rollouts and, after four updates, the same parameters bit for bit."""
+    import numpy as np
+    from imagesegmentation_amd import data
+    from imagesegmentation_amd.polyrl import a3c
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    dev = torch.device("cuda:0")
+    n = 32
+    ds = data.PolygonDataset.synthetic(16, image_size=32, prediction_size=32, max_timesteps=10, history_length=2, seed=30)
+    rs = np.random.RandomState(40)
+    idx = rs.randint(0, len(ds), [n])
+    images = ds._images[idx]
+    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
+    runs = {}
+    for reuse in (True, False):
+        env = BatchedPolygonEnv(ds, n, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=dev)
+        trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0, learning_rate=1e-3)
+        assert trainer.reuse_forward
+        trainer.reuse_forward = reuse
+        seen = []
+        for _ in range(4):
+            b = trainer.process(images, polygons)
+            seen.append({k: b[k].clone() for k in ("si", "a", "values", "rewards", "lengths")})
+        assert trainer._rollout["graph"] is not None
+        runs[reuse] = (seen, trainer.opt.flat_param.clone())
+    for a, b in zip(runs[True][0], runs[False][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(runs[True][1], runs[False][1])
