@@ -232,6 +232,7 @@ def bench_reinforce(n_envs, steps, device, rank, dtype):
     # beyond 64 environments, each rolled to a random start vertex): a fresh draw per rollout, no host work
     runner = BatchedReinforce(policy, ds, n_envs, device_pool=True, pool_seed=20 + rank)
     runner.step()
+    runner.rollout()  # (untimed like the step: a rollout by itself keeps nothing for an update - other kernel variants)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -844,7 +845,7 @@ class StubWorkload:
         return None
 
     def reinforce_leg(self):
-        # bench_reinforce: one warm-up step, 3 rollouts (no exchange), 3 steps with the update
+        # bench_reinforce: one warm-up step, 1 + 3 rollouts (no exchange), 3 steps with the update
         for _ in range(1 + 3):
             self._rl_update()
         return {"ms_per_step": 1.0 + self.rank, "rollouts_per_s_rollout_only": 0.0, "envs": self.share["rl_envs"]}
