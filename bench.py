@@ -255,32 +255,32 @@ def bench_a3c(n_envs, steps, device, rank, dtype):
     at 32 x 32, rollouts of at most 10 steps) over n_envs lock-stepped environments: env-steps per second."""
     from imagesegmentation_amd import data
     from imagesegmentation_amd.polyrl import a3c
-    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv
+    from imagesegmentation_amd.polyrl.batched_env import BatchedPolygonEnv, DevicePolygonPool
     ds = data.PolygonDataset.synthetic(64, image_size=32, prediction_size=32, max_timesteps=10, history_length=2,
                                        seed=30 + rank)
-    rs = np.random.RandomState(40 + rank)
-    idx = rs.randint(0, len(ds), [n_envs])
-    images = ds._images[idx]
-    polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
     env = BatchedPolygonEnv(ds, n_envs, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=device)
     trainer = a3c.A3C(env, compute_dtype=dtype, seed=0)
+    # episodes are drawn from the device-resident copy of the dataset, a fresh draw per update (each polygon rolled to
+    # a random start vertex), as in the REINFORCE leg: no host work at reset
+    pool = DevicePolygonPool(ds, device, dtype=torch.float32, vcap=2 + a3c.A3C.TIMESTEP_LIMIT + 1, seed=40 + rank)
     # (no solver search for any library convolution a fallback path of this leg might still take)
     find = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = False
     # untimed: the first update launches its acting loop step by step, the second captures it as a graph
     # (A3C.rollout_graph), from the third on it is replayed
     for _ in range(3):
-        trainer.process(images, polygons)
+        trainer.process(device_batch=pool.sample(n_envs))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     env_steps = 0
     for _ in range(steps):
-        trainer.process(images, polygons)
+        trainer.process(device_batch=pool.sample(n_envs))
         env_steps += trainer.last_env_steps
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     torch.backends.cudnn.benchmark = find
-    return {"envs": n_envs, "size": 32, "filters": 32, "env_steps_per_s": env_steps / el, "ms_per_update": el / steps * 1e3,
+    return {"envs": n_envs, "size": 32, "filters": 32, "episode_source": "device pool",
+            "env_steps_per_s": env_steps / el, "ms_per_update": el / steps * 1e3,
             "loss": trainer.last["loss"]}
 
 

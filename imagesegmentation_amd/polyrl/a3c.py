@@ -323,12 +323,14 @@ class A3C:
                               self.local_network.compute_dtype == torch.bfloat16 and
                               not os.environ.get("ISG_NO_FORWARD_REUSE"))
 
-    def pull_batch(self, images=None, polygons=None):
-        """Every environment from reset to its terminal step or the step limit."""
+    def pull_batch(self, images=None, polygons=None, device_batch=None):
+        """Every environment from reset to its terminal step or the step limit.  ``device_batch``: episodes that are
+        on the device already (``DevicePolygonPool.sample``: no host work at reset), else ``images`` / ``polygons``
+        from the host, else a draw from the environment's dataset."""
         env, pi = self.env, self.local_network
         N, T, P = env.num_envs, self.TIMESTEP_LIMIT, env.size
         dev = env.device
-        state = env.reset(images=images, polygons=polygons)
+        state = env.reset(images=images, polygons=polygons, device_batch=device_batch)
         if pi.filters > 16 and dev.type == "cuda":
             return self._pull_batch_stepper(state)
         c, h = pi.get_initial_features(N)
@@ -417,16 +419,16 @@ class A3C:
         return dict(si=r["obs"], a=r["actions"], values=r["values"], rewards=r["rewards"], lengths=r["lengths"],
                     terminal=env.done.clone(), forward=r["rec"].record() if self.reuse_forward else None)
 
-    def process(self, images=None, polygons=None):
+    def process(self, images=None, polygons=None, device_batch=None):
         with self.derived:
-            batch = self._process(images, polygons)
+            batch = self._process(images, polygons, device_batch)
         if isinstance(self.derived, ops.DerivedWeights):
             self.derived.compile()
         return batch
 
-    def _process(self, images=None, polygons=None):
+    def _process(self, images=None, polygons=None, device_batch=None):
         pi = self.local_network
-        batch = self.pull_batch(images, polygons)
+        batch = self.pull_batch(images, polygons, device_batch)
         N, T = batch["a"].shape
         adv, r = process_rollouts(batch["rewards"], batch["values"], batch["lengths"], self.gamma, self.lambda_)
         live = torch.arange(T, device=adv.device)[None, :] < batch["lengths"][:, None]
