@@ -730,12 +730,13 @@ def copy_slice(dst, src):
     return dst
 
 
-def pad_channels(x, cout):
+def pad_channels(x, cout, out=None):
     """x float32 or bfloat16 [.., cin] -> bfloat16 [.., cout] with zero channels cin..: conversion and padding in one
     pass (an observation for a first encoder layer on the square kernels, ``conv32_pack_padded``)."""
     assert x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] <= cout and cout % 8 == 0
     x = x.contiguous()
-    y = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.bfloat16, device=x.device) if out is None else out
+    assert y.dtype == torch.bfloat16 and y.is_contiguous() and tuple(y.shape) == tuple(x.shape[:-1]) + (cout,)
     rc = _lib.lib().isg_pad_channels(_lib.ptr(x), dtype_code(x.dtype), int(x.shape[-1]), _lib.ptr(y), int(cout),
                                      x.numel() // x.shape[-1], _lib.current_stream())
     _lib.check(rc, "isg_pad_channels")
@@ -899,11 +900,12 @@ def conv32_padded_supported(w_hwio, dtype, device):
             _lib.lib().isg_conv32_packed_elems(int(kh)) > 0)
 
 
-@_timed_as(lambda x, wimg, bias, ks, relu: "conv32[%dx%d C=%d]" % (ks, ks, x.shape[-1]))
-def conv32(x, wimg, bias, ks, relu):
+@_timed_as(lambda x, wimg, bias, ks, relu, out=None: "conv32[%dx%d C=%d]" % (ks, ks, x.shape[-1]))
+def conv32(x, wimg, bias, ks, relu, out=None):
     B, H, W, c = x.shape
     assert c in (16, 32) and x.dtype == torch.bfloat16 and x.is_contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    assert y.shape == x.shape and y.dtype == x.dtype and y.is_contiguous() and y.data_ptr() != x.data_ptr()
     fn = _lib.lib().isg_conv32 if c == 32 else _lib.lib().isg_conv16
     rc = fn(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)), _lib.ptr(y),
             _lib.current_stream())

@@ -32,7 +32,8 @@ from ..convLSTM import (ConvLSTMCell, LSTMStateTuple, SequenceInput, WideRecorde
                         glorot_uniform_)
 from ..optim import FlatAdam
 from ..polyrnn import decode
-from ..polyrnn.Model import _DenseHead, _EncoderChain, _head_weights, conv2d_same_relu, encoder_chain_supported
+from ..polyrnn.Model import (_DenseHead, _EncoderChain, _RecordedEncoder, _head_weights, conv2d_same_relu,
+                             encoder_chain_supported)
 
 
 def discount(x, gamma):
@@ -202,8 +203,24 @@ class LSTMPolicy:
         """Zero LSTM state (c float32, h compute dtype), reference polyrl/a3c/model.py:27-29,46-48."""
         return self.lstm.zero_state(num_envs, self.device)
 
-    def _encode(self, x):
+    def encoder_keeps(self, x):
+        """Whether ``_encode(x, keep=)`` can keep its layers' outputs for ``forward(recorded_encoder=)``: the padded
+        first layer and the square kernels, bf16 on the GPU."""
+        dt = self.compute_dtype
+        return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and dt == torch.bfloat16 and
+                ops.conv32_padded_supported(self.convs[0][0], dt, x.device) and
+                all(ops.conv32_supported(w, dt, x.device) for w, _ in self.convs[1:]))
+
+    def _encode(self, x, keep=None):
         # [R, H, W, C] -> [R, H, W, 32]
+        # keep = (padded-input buffer, [one output buffer per layer]): an acting step writes its layers there, for
+        # the update that follows under the same weights (``forward(recorded_encoder=)``)
+        if keep is not None:
+            y = ops.pad_channels(x, self.convs[0][0].shape[3], out=keep[0])
+            for k, (w, b) in enumerate(self.convs):
+                wimg = ops.conv32_pack_padded(w) if k == 0 else ops.conv32_pack(w)
+                y = ops.conv32(y, wimg, b.detach().float().contiguous(), w.shape[0], True, out=keep[1][k])
+            return y
         # the same layer routine as the polygon-RNN encoder: 32 -> 32 layers run on the conv32 kernels in bf16
         dt = self.compute_dtype
         w0 = self.convs[0][0]
@@ -218,13 +235,21 @@ class LSTMPolicy:
             y = conv2d_same_relu(y, w, b, dt)
         return y.contiguous()
 
-    def forward(self, x, state, recorded=None):
+    def forward(self, x, state, recorded=None, recorded_encoder=None):
         """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out.
         ``recorded``: the recurrence's pass over these very observations from the zero state with the present weights
-        (``WideRecorder.record()`` of the rollout that produced them); the recurrence's node adopts it."""
+        (``WideRecorder.record()`` of the rollout that produced them); the recurrence's node adopts it.
+        ``recorded_encoder``: likewise the encoder's pass, (padded observations, [the layers' outputs]), each
+        time-major [T, N, H, W, 32] (``_encode(keep=)`` of the acting steps)."""
         N, T = x.shape[0], x.shape[1]
-        feats = self._encode(x.reshape((N * T,) + tuple(x.shape[2:]))).reshape((N, T) + tuple(x.shape[2:4]) + (32,))
-        seq = SequenceInput(x_seq=feats.transpose(0, 1))
+        if recorded_encoder is not None:
+            x4, ys = recorded_encoder
+            rows = lambda a: a.view((T * N,) + tuple(a.shape[2:]))
+            feats_tm = _RecordedEncoder.apply((rows(x4), [rows(y) for y in ys]), *[p for wb in self.convs for p in wb])
+            seq = SequenceInput(x_seq=feats_tm.view((T, N) + tuple(feats_tm.shape[1:])))
+        else:
+            feats = self._encode(x.reshape((N * T,) + tuple(x.shape[2:]))).reshape((N, T) + tuple(x.shape[2:4]) + (32,))
+            seq = SequenceInput(x_seq=feats.transpose(0, 1))
         seq.recorded = recorded
         out, final = dynamic_rnn(self.lstm, seq, initial_state=LSTMStateTuple(*state), time_major=False)
         logits, vf = self._heads(out.reshape(N * T, -1))
@@ -274,12 +299,12 @@ class LSTMPolicy:
             a = decode.sample_rows(logits.contiguous(), seed=self._seed * 1000003 + self._sample_calls)
         return a.long(), vf
 
-    def act_step_xy(self, ob, stepper, row_offset_dev, grid_side):
+    def act_step_xy(self, ob, stepper, row_offset_dev, grid_side, keep=None):
         """``act_step`` for a loop that may be captured as a graph: the action arrives as int32 (x, y) [N, 2] from the
         sampling launch itself and the sampling stream's position is a device counter (int64 scalar, advanced here by
         N), so that a replay draws new numbers.  Returns ((x, y), value [N])."""
         with torch.no_grad():
-            feats = self._encode(ob)
+            feats = self._encode(ob, keep=keep)  # (keep: see ``_encode``)
             logits, vf = self._heads(stepper.step(feats).reshape(ob.shape[0], -1))
             xy = decode.sample_actions(logits.contiguous(), seed=self._seed, grid_side=grid_side,
                                        row_offset_dev=row_offset_dev)
@@ -322,6 +347,9 @@ class A3C:
         self.reuse_forward = (self.opt.flat_param.is_cuda and self.local_network.filters > 16 and
                               self.local_network.compute_dtype == torch.bfloat16 and
                               not os.environ.get("ISG_NO_FORWARD_REUSE"))
+        #: likewise the encoder's pass (its weight gradients then sum the rows step by step instead of environment by
+        #: environment: the same sums in another order of float additions)
+        self.reuse_encoder = self.reuse_forward and not os.environ.get("ISG_NO_ENCODER_REUSE")
 
     def pull_batch(self, images=None, polygons=None, device_batch=None):
         """Every environment from reset to its terminal step or the step limit.  ``device_batch``: episodes that are
@@ -365,7 +393,8 @@ class A3C:
         where = tuple(t.data_ptr() for t in tensors) + (N, T, P)
         if r is None or r["where"] != where:
             r = self._rollout = dict(
-                where=where, graph=None, rec=pi.recorder(N, T) if self.reuse_forward else pi.stepper(N), offset=torch.zeros([], dtype=torch.int64, device=dev),
+                where=where, graph=None, rec=pi.recorder(N, T) if self.reuse_forward else pi.stepper(N),
+                enc=self._encoder_buffers(state, N, T) if self.reuse_forward and self.reuse_encoder else None, offset=torch.zeros([], dtype=torch.int64, device=dev),
                 obs=torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev),
                 xy=torch.zeros([N, T, 2], dtype=torch.int32, device=dev),
                 actions=torch.zeros([N, T], dtype=torch.int64, device=dev),
@@ -380,7 +409,8 @@ class A3C:
             for t in range(T):
                 active = ~env.done
                 r["obs"][:, t] = state
-                xy, v = pi.act_step_xy(state, r["rec"], r["offset"], P)
+                keep = None if r["enc"] is None else (r["enc"][0][t], [y[t] for y in r["enc"][1]])
+                xy, v = pi.act_step_xy(state, r["rec"], r["offset"], P, keep=keep)
                 r["xy"][:, t], r["values"][:, t] = xy, v
                 r["lengths"] += active.to(torch.int32)
                 state, reward, _ = env.step(xy, host_sync=False)
@@ -417,7 +447,18 @@ class A3C:
             body()
             r["warm"] = True
         return dict(si=r["obs"], a=r["actions"], values=r["values"], rewards=r["rewards"], lengths=r["lengths"],
-                    terminal=env.done.clone(), forward=r["rec"].record() if self.reuse_forward else None)
+                    terminal=env.done.clone(), forward=r["rec"].record() if self.reuse_forward else None,
+                    encoder=r["enc"] if self.reuse_forward and self.reuse_encoder else None)
+
+    def _encoder_buffers(self, state, N, T):
+        """Where the acting steps keep the encoder's padded input and layer outputs for the update, time-major
+        [T, N, H, W, 32] each; None where the encoder does not run on the kernels that can keep them."""
+        pi = self.local_network
+        if not pi.encoder_keeps(state):
+            return None
+        shape = [T, N] + list(state.shape[1:3]) + [int(pi.convs[0][0].shape[3])]
+        new = lambda: torch.empty(shape, dtype=torch.bfloat16, device=state.device)
+        return new(), [new() for _ in pi.convs]
 
     def process(self, images=None, polygons=None, device_batch=None):
         with self.derived:
@@ -434,7 +475,8 @@ class A3C:
         live = torch.arange(T, device=adv.device)[None, :] < batch["lengths"][:, None]
         self.opt.zero_grad()
         # (the weights have not changed since the rollout: the update adopts its pass of the recurrence)
-        logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N), recorded=batch.get("forward"))
+        logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N), recorded=batch.get("forward"),
+                                   recorded_encoder=batch.get("encoder"))
         loss, parts = a3c_loss(logits.reshape(N * T, -1), vf.reshape(-1), batch["a"].reshape(-1), adv.reshape(-1),
                                r.reshape(-1), live.reshape(-1))
         (loss / N).backward()

@@ -188,6 +188,28 @@ class _EncoderChain(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class _RecordedEncoder(torch.autograd.Function):
+    """``_EncoderChain`` (padded first layer) over a forward pass that has already run: ``recorded`` = (padded input,
+    the layers' outputs), each [rows, H, W, C] - a rollout's acting steps ran these very launches on these very
+    observations with the present weights and kept their outputs (polyrl/a3c: ``LSTMPolicy._encode(keep=)``).  The
+    forward hands out the top layer's kept output; the backward is the chain's."""
+
+    @staticmethod
+    def forward(ctx, recorded, *params):
+        x4, ys = recorded
+        ws, bs = params[0::2], params[1::2]
+        ctx.padded_first = True
+        ctx.save_for_backward(x4, *ys, *ws)
+        ctx.biases = [b.detach() for b in bs]
+        ctx.n = len(ws)
+        ctx.dtypes = [p.dtype for p in params]
+        return ys[-1].view_as(ys[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _EncoderChain.backward(ctx, dy)
+
+
 def encoder_chain_supported(x_nhwc, encoder, dtype):
     """Whether ``_EncoderChain`` takes this encoder: an input that needs no gradient, a first layer for the
     isg_conv_in kernels (or, padded, for the square ones) and at least one more layer, all of those for the isg_conv32 / isg_conv16 kernels."""

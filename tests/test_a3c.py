@@ -214,8 +214,8 @@ def test_update_that_adopts_the_rollouts_recurrence_equals_the_update_that_runs_
     for reuse in (True, False):
         env = BatchedPolygonEnv(ds, n, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=dev)
         trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0, learning_rate=1e-3)
-        assert trainer.reuse_forward
-        trainer.reuse_forward = reuse
+        assert trainer.reuse_forward and trainer.reuse_encoder
+        trainer.reuse_forward, trainer.reuse_encoder = reuse, False
         seen = []
         for _ in range(4):
             b = trainer.process(images, polygons)
@@ -226,6 +226,23 @@ def test_update_that_adopts_the_rollouts_recurrence_equals_the_update_that_runs_
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert torch.equal(runs[True][1], runs[False][1])
+    # the encoder's pass adopted as well: its weight gradients sum the same rows step by step instead of environment
+    # by environment - the first rollout is the same, the parameters after one update agree to float rounding
+    first = {}
+    for enc in (True, False):
+        env = BatchedPolygonEnv(ds, n, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=dev)
+        trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0, learning_rate=1e-3)
+        trainer.reuse_encoder = enc
+        b = trainer.process(images, polygons)
+        first[enc] = ({k: b[k].clone() for k in ("si", "a", "values", "rewards", "lengths")},
+                      trainer.opt.flat_param.clone(), dict(trainer.last))
+    for k in first[True][0]:
+        assert torch.equal(first[True][0][k], first[False][0][k]), k
+    assert abs(first[True][2]["loss"] - first[False][2]["loss"]) <= 1e-6 * abs(first[False][2]["loss"])
+    assert abs(first[True][2]["grad_global_norm"] - first[False][2]["grad_global_norm"]) <= \
+        1e-3 * first[False][2]["grad_global_norm"]
+    moved = (first[False][1] - runs[False][1]).abs().max()  # (any scale of the parameters: a later state of them)
+    assert float((first[True][1] - first[False][1]).abs().max()) <= 2e-4 and float(moved) > 0
 
 
 @pytest.mark.gpu
