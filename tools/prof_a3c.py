@@ -25,12 +25,18 @@ def run():
     polygons = [np.roll(ds._vertices[i], rs.randint(len(ds._vertices[i])), axis=0) for i in idx]
     env = BatchedPolygonEnv(ds, n, end_token=False, max_steps=a3c.A3C.TIMESTEP_LIMIT, device=dev)
     trainer = a3c.A3C(env, compute_dtype=torch.bfloat16, seed=0)
-    trainer.process(images, polygons)
+    if os.environ.get("ISG_A3C_POOL"):  # episodes drawn on the device, as the bench leg does
+        from imagesegmentation_amd.polyrl.batched_env import DevicePolygonPool
+        pool = DevicePolygonPool(ds, dev, dtype=torch.float32, vcap=2 + a3c.A3C.TIMESTEP_LIMIT + 1, seed=41)
+        update = lambda: trainer.process(device_batch=pool.sample(n))
+    else:
+        update = lambda: trainer.process(images, polygons)
+    update()
     torch.cuda.synchronize()
     times = []
     for _ in range(int(os.environ.get("ISG_A3C_UPDATES", "3"))):
         t0 = time.perf_counter()
-        trainer.process(images, polygons)
+        update()
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
         print("update ms %.3f" % times[-1])
