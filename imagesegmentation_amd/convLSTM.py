@@ -872,8 +872,8 @@ class _WideSequenceFunction(torch.autograd.Function):
             ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
             ctx.batch_major = T > 1 and B > 1 and x_seq.transpose(0, 1).is_contiguous()
             ctx.set_materialize_grads(False)
-            return out, torch.cat([Cs[s][t_run] for s in range(k)], dim=-1), \
-                torch.cat([Hs[s][t_run] for s in range(k)], dim=-1)
+            # (the final state of an adopted pass is not joined: it sits in the recorder, per group, for who wants it)
+            return out, None, None
         groups = _wide_groups(cell, C)
         cs = groups[0][1].cs
         keep = not getattr(ctx, "forward_only", False)  # without a backward pass no gates are stored

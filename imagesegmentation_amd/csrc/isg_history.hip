@@ -161,6 +161,47 @@ extern "C" int isg_env_step(const int32_t* actions, const int32_t* true_vertices
     return isg::check_launch("env_step_kernel");
 }
 
+namespace {
+// one thread per rollout: the two backward scans of reference polyrl/a3c/a3c.py:15-32 in double, each sum rounded
+// as written (no fused multiply-add: the host code this replaces rounds the product first)
+__global__ __launch_bounds__(256) void gae_kernel(const double* __restrict__ rewards, const float* __restrict__ values,
+                                                  const int32_t* __restrict__ lengths, const double* __restrict__ boot,
+                                                  int N, int T, double gamma, double gl, double* __restrict__ adv,
+                                                  double* __restrict__ ret) {
+#pragma clang fp contract(off)
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    int L = lengths[n];
+    L = L < 0 ? 0 : (L > T ? T : L);
+    const double b = boot ? boot[n] : 0.0;
+    double acc_a = 0.0, acc_r = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)n * T + t;
+        if (t >= L) {
+            adv[o] = 0.0, ret[o] = 0.0;
+            continue;
+        }
+        const bool last = t == L - 1;
+        const double r = rewards[o], v = (double)values[o], v_next = last ? b : (double)values[o + 1];
+        const double td = r + gamma * v_next - v;
+        const double r_in = last ? r + gamma * b : r;
+        acc_a = td + gl * acc_a;
+        acc_r = r_in + gamma * acc_r;
+        adv[o] = acc_a, ret[o] = acc_r;
+    }
+}
+}  // namespace
+
+extern "C" int isg_gae(const double* rewards, const float* values, const int32_t* lengths, const double* bootstrap, int N,
+                       int T, double gamma, double lambda, double* advantages, double* returns, void* stream) {
+    ISG_REQUIRE(N >= 0 && T >= 1, ISG_EINVAL, "isg_gae: N=%d T=%d", N, T);
+    if (N == 0) return ISG_OK;
+    ISG_REQUIRE(rewards && values && lengths && advantages && returns, ISG_EINVAL, "isg_gae: null pointer");
+    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), rewards, values,
+                       lengths, bootstrap, N, T, gamma, gamma * lambda, advantages, returns);
+    return isg::check_launch("gae_kernel");
+}
+
 extern "C" int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out,
                                   int out_channels, int out_offset, void* stream) {
     ISG_REQUIRE(n >= 0 && size >= 1 && hist >= 0, ISG_EINVAL, "isg_history_frames: bad sizes");

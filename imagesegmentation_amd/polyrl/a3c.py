@@ -63,6 +63,18 @@ def process_rollouts(rewards, values, lengths, gamma, lambda_=1.0, bootstrap=Non
     t >= length are ignored on input and zero on output.  float64 throughout."""
     N, T = rewards.shape
     dev = rewards.device
+    if (rewards.is_cuda and rewards.dtype == torch.float64 and values.dtype == torch.float32 and
+            lengths.dtype == torch.int32 and (bootstrap is None or bootstrap.dtype == torch.float64)):
+        # one launch (isg_gae): the same sums in the same order, one thread per rollout
+        from .. import _lib
+        adv = torch.empty([N, T], dtype=torch.float64, device=dev)
+        ret = torch.empty([N, T], dtype=torch.float64, device=dev)
+        rc = _lib.lib().isg_gae(_lib.ptr(rewards.contiguous()), _lib.ptr(values.contiguous()),
+                                _lib.ptr(lengths.contiguous()), _lib.ptr(bootstrap.contiguous()) if bootstrap is not None
+                                else None, N, T, float(gamma), float(lambda_), _lib.ptr(adv), _lib.ptr(ret),
+                                _lib.current_stream())
+        _lib.check(rc, "isg_gae")
+        return adv, ret
     live = torch.arange(T, device=dev)[None, :] < lengths[:, None]
     rewards = torch.where(live, rewards.double(), torch.zeros([], dtype=torch.float64, device=dev))
     values = torch.where(live, values.double(), torch.zeros([], dtype=torch.float64, device=dev))
@@ -238,7 +250,8 @@ class LSTMPolicy:
     def forward(self, x, state, recorded=None, recorded_encoder=None):
         """x [N, T, H, W, C], state (c, h) -> logits [N, T, K] float32, vf [N, T] float32, state_out.
         ``recorded``: the recurrence's pass over these very observations from the zero state with the present weights
-        (``WideRecorder.record()`` of the rollout that produced them); the recurrence's node adopts it.
+        (``WideRecorder.record()`` of the rollout that produced them); the recurrence's node adopts it (state_out is
+        then (None, None): the final state stays in the recorder).
         ``recorded_encoder``: likewise the encoder's pass, (padded observations, [the layers' outputs]), each
         time-major [T, N, H, W, 32] (``_encode(keep=)`` of the acting steps)."""
         N, T = x.shape[0], x.shape[1]

@@ -111,6 +111,13 @@ int isg_env_step(const int32_t* actions, const int32_t* true_vertices, int true_
                  int end_token, int32_t* rec_points, int32_t* rec_actions, int32_t* rec_lengths, int T, int t,
                  void* stream);
 
+/* Advantages and returns of N rollouts of at most T steps (reference polyrl/a3c/a3c.py:11-32: td_t = r_t +
+ * gamma v_{t+1} - v_t, advantage = discount(td, gamma lambda), return = discount(r ++ bootstrap, gamma)), one
+ * launch: rewards double [N][T], values float [N][T], lengths int32 [N], bootstrap double [N] or NULL (0) - the value
+ * after a rollout's last step; advantages / returns double [N][T], zero at t >= lengths[n]. */
+int isg_gae(const double* rewards, const float* values, const int32_t* lengths, const double* bootstrap, int N, int T,
+            double gamma, double lambda, double* advantages, double* returns, void* stream);
+
 /* ---- ConvLSTM cell ------------------------------------------------------------------------
  * One step of the reference cell (reference convLSTM.py:26-45):
  *     y = conv(h_prev, W_h, SAME) + conv(x, W_x, SAME) + b ;  j, i, f, o = split(y, 4)

@@ -269,3 +269,30 @@ def test_updates_on_episodes_drawn_on_the_device():
     assert trainer._rollout["graph"] is not None
     assert not torch.equal(firsts[2], firsts[3])                      # a fresh draw per update
     assert trainer.last["loss"] == trainer.last["loss"]               # (not NaN)
+
+
+@pytest.mark.gpu
+def test_advantages_in_one_launch_against_the_reference_scan():
+    """isg_gae (process_rollouts on device tensors in the dtypes a rollout holds) against the reference's per-rollout
+    scan restated in numpy, with and without a bootstrap value, lengths 0 .. T."""
+    import numpy as np
+    from imagesegmentation_amd.polyrl import a3c
+    rs = np.random.RandomState(3)
+    N, T = 300, 10
+    rewards, values, boot = rs.rand(N, T), rs.randn(N, T).astype(np.float32), rs.rand(N)
+    lengths = rs.randint(0, T + 1, [N]).astype(np.int32)
+    lengths[:3] = (0, 1, T)
+    d = "cuda:0"
+    for b in (None, boot):
+        adv, ret = a3c.process_rollouts(torch.tensor(rewards, device=d), torch.tensor(values, device=d),
+                                        torch.tensor(lengths, device=d), 0.99, 0.95,
+                                        None if b is None else torch.tensor(b, device=d))
+        assert adv.dtype == torch.float64 and ret.dtype == torch.float64
+        adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
+        for n in range(N):
+            l = int(lengths[n])
+            assert not adv[n, l:].any() and not ret[n, l:].any()
+            if l:
+                radv, rret = oa.process_rollout(rewards[n, :l], values[n, :l].astype(np.float64),
+                                                0.0 if b is None else b[n], 0.99, 0.95)
+                assert np.allclose(adv[n, :l], radv, rtol=0, atol=1e-12) and np.allclose(ret[n, :l], rret, rtol=0, atol=1e-12)
