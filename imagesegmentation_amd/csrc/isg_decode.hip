@@ -461,6 +461,81 @@ __global__ __launch_bounds__(256) void sum_slices_bias_kernel(const float* __res
 }  // namespace
 
 namespace {
+// One wave per row of the actor-critic loss (reference polyrl/a3c/a3c.py:201-216): log-softmax of the row, the
+// chosen action's log-probability and the row's entropy in two passes over the logits (online max / sum, then
+// sum of p z), and the row's three weighted contributions:
+//   terms[row] = w * (-logp[a] * adv,  0.5 * (vf - ret)^2,  H)        stats[row] = (lse, H)
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void a3c_loss_fwd_kernel(
+    const T* __restrict__ logits, const float* __restrict__ vf, const int* __restrict__ actions,
+    const float* __restrict__ adv, const float* __restrict__ ret, const unsigned char* __restrict__ live, int rows,
+    int cols, float* __restrict__ terms, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    float m = -INFINITY, s = 0.0f;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = ld(z, c);
+        if (v > m) {
+            s = s * expf(m - v) + 1.0f;
+            m = v;
+        } else if (v != -INFINITY) {
+            s += expf(v - m);
+        }
+    }
+    const float gm = wave_max(m);
+    s = m == -INFINITY ? 0.0f : s * expf(m - gm);
+    s = wave_sum(s);
+    const float lse = gm + logf(s);
+    float pz = 0.0f;  // sum of p z over the row: H = lse - sum p z
+    for (int c = lane; c < cols; c += 64) {
+        const float v = ld(z, c);
+        if (v != -INFINITY) pz += expf(v - lse) * v;
+    }
+    pz = wave_sum(pz);
+    if (lane == 0) {
+        const float w = live == nullptr || live[row] ? 1.0f : 0.0f;
+        const int a = actions[row];
+        const float logp_a = (a >= 0 && a < cols) ? ld(z, a) - lse : NAN;
+        const float H = lse - pz;
+        const float dv = vf[row] - ret[row];
+        terms[3 * row] = w * (-logp_a * adv[row]);
+        terms[3 * row + 1] = w * (0.5f * dv * dv);
+        terms[3 * row + 2] = w * H;
+        stats[2 * row] = lse, stats[2 * row + 1] = H;
+    }
+}
+
+// dlogits[row][k] = w (g_pi * adv * (p_k - [k = a]) - g_ent * p_k (logp_k + H)),  dvf[row] = w g_vf (vf - ret)
+// with upstream = (g_pi, g_vf, g_ent) read from device memory (no host round trip for the loss's own scale).
+template <typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void a3c_loss_bwd_kernel(
+    const T* __restrict__ logits, const float* __restrict__ vf, const int* __restrict__ actions,
+    const float* __restrict__ adv, const float* __restrict__ ret, const unsigned char* __restrict__ live,
+    const float* __restrict__ stats, const float* __restrict__ upstream, int rows, int cols, T* __restrict__ dlogits,
+    float* __restrict__ dvf) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* z = logits + (size_t)row * cols;
+    T* d = dlogits + (size_t)row * cols;
+    const float w = live == nullptr || live[row] ? 1.0f : 0.0f;
+    const float g_pi = upstream[0], g_vf = upstream[1], g_ent = upstream[2];
+    const float lse = stats[2 * row], H = stats[2 * row + 1];
+    const int a = actions[row];
+    const float ca = w * g_pi * adv[row], ce = w * g_ent;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = ld(z, c);
+        const float logp = v - lse;
+        const float p = v == -INFINITY ? 0.0f : expf(logp);
+        float g = ca * (p - (c == a ? 1.0f : 0.0f));
+        if (p > 0.0f) g -= ce * p * (logp + H);
+        d[c] = (T)g;
+    }
+    if (lane == 0) dvf[row] = w * g_vf * (vf[row] - ret[row]);
+}
+
 constexpr int kColSumMaxBlocks = 256;
 
 // thread = column; a workgroup sums its share of the rows (every row read is 256 adjacent elements)
@@ -515,6 +590,45 @@ extern "C" int isg_column_sums(const void* x, long long rows, int cols, int dtyp
     if (rc != ISG_OK) return rc;
     hipLaunchKernelGGL(column_sums_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nblk, cols, out);
     return isg::check_launch("column_sums_finish_kernel");
+}
+
+extern "C" int isg_a3c_loss_fwd(const void* logits, const float* vf, const int32_t* actions, const float* adv,
+                                const float* ret, const unsigned char* live, int rows, int cols, int dtype,
+                                float* terms, float* stats, void* stream) {
+    int rc = check_rows("isg_a3c_loss_fwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && vf && actions && adv && ret && terms && stats, ISG_EINVAL, "isg_a3c_loss_fwd: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(a3c_loss_fwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), vf, actions,
+                           adv, ret, live, rows, cols, terms, stats);
+    else
+        hipLaunchKernelGGL(a3c_loss_fwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), vf, actions, adv, ret, live, rows, cols, terms,
+                           stats);
+    return isg::check_launch("a3c_loss_fwd_kernel");
+}
+
+extern "C" int isg_a3c_loss_bwd(const void* logits, const float* vf, const int32_t* actions, const float* adv,
+                                const float* ret, const unsigned char* live, const float* stats, const float* upstream3,
+                                int rows, int cols, int dtype, void* dlogits, float* dvf, void* stream) {
+    int rc = check_rows("isg_a3c_loss_bwd", rows, cols, dtype);
+    if (rc != ISG_OK) return rc;
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(logits && vf && actions && adv && ret && stats && upstream3 && dlogits && dvf, ISG_EINVAL,
+                "isg_a3c_loss_bwd: null pointer");
+    const dim3 grid((rows + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ISG_F32)
+        hipLaunchKernelGGL(a3c_loss_bwd_kernel<float>, grid, block, 0, s, static_cast<const float*>(logits), vf, actions,
+                           adv, ret, live, stats, upstream3, rows, cols, static_cast<float*>(dlogits), dvf);
+    else
+        hipLaunchKernelGGL(a3c_loss_bwd_kernel<__hip_bfloat16>, grid, block, 0, s,
+                           static_cast<const __hip_bfloat16*>(logits), vf, actions, adv, ret, live, stats, upstream3, rows,
+                           cols, static_cast<__hip_bfloat16*>(dlogits), dvf);
+    return isg::check_launch("a3c_loss_bwd_kernel");
 }
 
 extern "C" int isg_decode_begin(const int32_t* true_vertices, const int32_t* num_true, int B, int vmax, int hist, int T,

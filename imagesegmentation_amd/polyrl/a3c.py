@@ -110,9 +110,51 @@ def _discount_matrix(T, g, device):
     return m
 
 
+class _A3CLoss(torch.autograd.Function):
+    """The three sums of the loss below in three launches (isg_a3c_loss_fwd + isg_column_sums) and their gradient in
+    one (isg_a3c_loss_bwd), where the tensor form takes some forty small launches over the [R, K] logits: returns
+    float32 [3] = (policy loss, value loss, entropy), sums over the rows."""
+
+    @staticmethod
+    def forward(ctx, logits, vf, actions, adv, r, live):
+        from .. import _lib
+        R, K = logits.shape
+        z = logits.contiguous()
+        dev = z.device
+        vf32, adv32, r32 = vf.float().contiguous(), adv.float().contiguous(), r.float().contiguous()
+        a32 = actions.to(torch.int32).contiguous()
+        live8 = None if live is None else live.to(torch.uint8).contiguous()
+        terms = torch.empty([R, 3], dtype=torch.float32, device=dev)
+        stats = torch.empty([R, 2], dtype=torch.float32, device=dev)
+        rc = _lib.lib().isg_a3c_loss_fwd(_lib.ptr(z), _lib.ptr(vf32), _lib.ptr(a32), _lib.ptr(adv32), _lib.ptr(r32),
+                                         _lib.ptr(live8), R, K, ops.dtype_code(z.dtype), _lib.ptr(terms), _lib.ptr(stats),
+                                         _lib.current_stream())
+        _lib.check(rc, "isg_a3c_loss_fwd")
+        ctx.save_for_backward(z, vf32, a32, adv32, r32, stats)
+        ctx.live8, ctx.vf_dtype = live8, vf.dtype
+        return decode.column_sums(terms)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        z, vf32, a32, adv32, r32, stats = ctx.saved_tensors
+        R, K = z.shape
+        dlogits = torch.empty_like(z)
+        dvf = torch.empty([R], dtype=torch.float32, device=z.device)
+        rc = _lib.lib().isg_a3c_loss_bwd(_lib.ptr(z), _lib.ptr(vf32), _lib.ptr(a32), _lib.ptr(adv32), _lib.ptr(r32),
+                                         _lib.ptr(ctx.live8), _lib.ptr(stats), _lib.ptr(g.float().contiguous()), R, K,
+                                         ops.dtype_code(z.dtype), _lib.ptr(dlogits), _lib.ptr(dvf), _lib.current_stream())
+        _lib.check(rc, "isg_a3c_loss_bwd")
+        return dlogits, dvf.to(ctx.vf_dtype), None, None, None, None
+
+
 def a3c_loss(logits, vf, actions, adv, r, live=None):
     """Reference polyrl/a3c/a3c.py:201-216 over rows [R, K] (R = all steps of all rollouts); rows with
     ``live`` False contribute nothing.  Returns (loss, dict of the three parts), all sums."""
+    if logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and not os.environ.get("ISG_NO_FUSED_A3C_LOSS"):
+        sums = _A3CLoss.apply(logits, vf, actions, adv, r, live)
+        pi_loss, vf_loss, entropy = sums[0], sums[1], sums[2]
+        return pi_loss + 0.5 * vf_loss - entropy * 0.01, dict(pi_loss=pi_loss, vf_loss=vf_loss, entropy=entropy)
     logp = F.log_softmax(logits.float(), dim=-1)
     p = logp.exp()
     w = torch.ones_like(vf, dtype=torch.float32) if live is None else live.to(torch.float32)

@@ -336,6 +336,19 @@ int isg_sample_actions(const void* logits, int rows, int cols, int dtype, unsign
                        unsigned long long row_offset, const unsigned long long* row_offset_dev, int P,
                        int32_t* out_xy, void* stream);
 
+/* The actor-critic loss of reference polyrl/a3c/a3c.py:201-216 over rows = all steps of all rollouts, as per-row
+ * contributions (sum them with isg_column_sums): with p = softmax(logits[r]), a = actions[r], w = live[r] (NULL: 1),
+ *   terms[r] = w * (-log p[a] * adv[r],  0.5 * (vf[r] - ret[r])^2,  -sum_k p_k log p_k)       float [rows][3]
+ *   stats[r] = (log-sum-exp, entropy)                                                         float [rows][2]
+ * total loss = sum terms[.,0] + 0.5 * sum terms[.,1] - 0.01 * sum terms[.,2].
+ * isg_a3c_loss_bwd: from upstream3 = d loss / d (the three sums), DEVICE float [3], to dlogits `dtype` [rows][cols]
+ * and dvf float [rows]; logits `dtype` (float or bf16), vf / adv / ret float, actions int32, live uint8. */
+int isg_a3c_loss_fwd(const void* logits, const float* vf, const int32_t* actions, const float* adv, const float* ret,
+                     const unsigned char* live, int rows, int cols, int dtype, float* terms, float* stats, void* stream);
+int isg_a3c_loss_bwd(const void* logits, const float* vf, const int32_t* actions, const float* adv, const float* ret,
+                     const unsigned char* live, const float* stats, const float* upstream3, int rows, int cols, int dtype,
+                     void* dlogits, float* dvf, void* stream);
+
 /* out[c] = sum over rows of x[r][c] (float, overwritten; a fixed order of additions): the bias gradient of the dense
  * head, tf.gradients of the bias add in reference polyrnn/History2LargeExperiment.py:48-50, whose rows are every
  * (sample, step) of a batch - tens of thousands in a policy update.  x `dtype` [rows][cols];

@@ -296,3 +296,36 @@ def test_advantages_in_one_launch_against_the_reference_scan():
                 radv, rret = oa.process_rollout(rewards[n, :l], values[n, :l].astype(np.float64),
                                                 0.0 if b is None else b[n], 0.99, 0.95)
                 assert np.allclose(adv[n, :l], radv, rtol=0, atol=1e-12) and np.allclose(ret[n, :l], rret, rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_loss_against_the_tensor_form(dtype, monkeypatch):
+    """isg_a3c_loss_fwd / _bwd (a3c_loss on device tensors) against the same loss written with tensor operations in
+    float64: the three sums and the gradients of the logits and the values, with masked rows and an action column at
+    either end."""
+    from imagesegmentation_amd.polyrl import a3c
+    d = "cuda:0"
+    g = torch.Generator(device=d).manual_seed(4)
+    R, K = 777, 1024
+    logits = (torch.randn([R, K], device=d, generator=g) * 2).to(dtype).requires_grad_(True)
+    vf = torch.randn([R], device=d, generator=g).requires_grad_(True)
+    actions = torch.randint(0, K, [R], device=d, generator=g)
+    actions[0], actions[1] = 0, K - 1
+    adv = torch.randn([R], device=d, generator=g, dtype=torch.float64)
+    ret = torch.randn([R], device=d, generator=g, dtype=torch.float64)
+    live = torch.rand([R], device=d, generator=g) > 0.3
+    loss, parts = a3c.a3c_loss(logits, vf, actions, adv, ret, live)
+    (loss / 7).backward()
+    z64 = logits.detach().double().requires_grad_(True)
+    v64 = vf.detach().double().requires_grad_(True)
+    monkeypatch.setenv("ISG_NO_FUSED_A3C_LOSS", "1")
+    ref, rparts = a3c.a3c_loss(z64, v64, actions, adv, ret, live)
+    (ref / 7).backward()
+    tol = 6e-3 if dtype == torch.bfloat16 else 1e-5  # (bf16 gradients: one rounding, 2^-8 of the value)
+    for k in ("pi_loss", "vf_loss", "entropy"):
+        assert abs(float(parts[k]) - float(rparts[k])) <= 1e-4 * abs(float(rparts[k])) + 1e-3, k
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-3
+    assert float((logits.grad.double() - z64.grad).abs().max()) <= tol * float(z64.grad.abs().max())
+    assert float((vf.grad.double() - v64.grad).abs().max()) <= 1e-6
+    assert float(logits.grad[~live].abs().max()) == 0.0 and float(vf.grad[~live].abs().max()) == 0.0
