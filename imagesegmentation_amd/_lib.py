@@ -39,6 +39,7 @@ SIGNATURES = {
     "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),
     "isg_relu_bwd_bias": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp, _vp]),
+    "isg_relu_bwd_bias_strided": (_int, [_vp, _vp, _ll, _ll, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_relu_bwd_bias_static": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp]),
     "isg_relu_bwd_bias_static_init": (_int, []),
     "isg_conv_in_packed_elems": (_ll, [_int, _int]),
@@ -51,6 +52,7 @@ SIGNATURES = {
     "isg_conv32_pack": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_conv32_pack_padded": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "isg_conv32": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp]),
+    "isg_conv32_strided": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _ll, _vp]),
     "isg_conv32_wgrad_workspace_bytes": (_ll, [_int]),
     "isg_conv32_wgrad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_conv16_packed_elems": (_ll, [_int]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "isg_decode_begin": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "isg_decode_polygons": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_sum_slices_bias": (_int, [_vp, _int, _int, _int, _vp, _int, _vp, _vp]),
+    "isg_rows_dot": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "isg_pad_channels": (_int, [_vp, _int, _int, _vp, _int, _ll, _vp]),
     "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),
     "isg_refresh_derived": (_int, [_vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _int, _vp, _vp, _vp, _vp]),

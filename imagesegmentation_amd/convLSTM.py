@@ -607,8 +607,10 @@ class WideRecorder:
                    list(torch.empty([T, B, H, W, Fh], dtype=torch.float32, device=device).unbind(0)) for _ in range(k)]
         self.Gs = [torch.empty([T] + ops.saved_shape(B, H, W, Fh, self.layout), dtype=dt, device=device)
                    for _ in range(k)]
-        self.out = torch.empty([B, T, H, W, F], dtype=dt, device=device)
-        self.step_out = torch.empty([B, H, W, F], dtype=dt, device=device)
+        # the joint outputs, stored time-major (a step's output is then one contiguous block: what ``step`` returns)
+        # and handed to the update as the batch-major view of the same memory
+        self.out_tm = torch.empty([T, B, H, W, F], dtype=dt, device=device)
+        self.out = self.out_tm.transpose(0, 1)
         self.t = 0
 
     def reset(self):
@@ -616,24 +618,32 @@ class WideRecorder:
         the zero state are never written)."""
         self.t = 0
 
+    def input_slots(self):
+        """[T, B, H, W, C]: where the steps' inputs live, the first C channels of the joint input's wider pixels.  A
+        producer that can write pixels that far apart (``ops.conv32(out=)``) fills ``input_slots()[t]`` itself and hands
+        that very view to ``step``, which then copies nothing."""
+        return self.xw[..., :self.C]
+
     def step(self, x):
-        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step (a buffer the next step overwrites)."""
+        """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step (its block of the kept outputs)."""
         Fh, C, F, t, T = ops.F_HIDDEN, self.C, self.cell._filters, self.t, self.T
         if t >= T:
             raise RuntimeError("the recorder holds %d steps" % T)
         groups = _wide_groups(self.cell, C)
         xw = self.xw[t]
         _, H, W, _ = xw.shape
-        ops.copy_slice(xw[..., :C], x if x.dtype == xw.dtype else x.to(xw.dtype))
+        slot = xw[..., :C]
+        if not (x.data_ptr() == slot.data_ptr() and x.stride() == slot.stride() and x.dtype == xw.dtype):
+            ops.copy_slice(slot, x if x.dtype == xw.dtype else x.to(xw.dtype))  # (else: written in place, ``input_slots``)
         for s in range(1, self.k):
             ops.copy_slice(xw[..., C + Fh * (s - 1):C + Fh * s], self.Hs[s][t])
         for s in range(self.k):
             ops.cell_fwd(xw, self.Hs[0][t], self.Cs[s][t], groups[s][1], None, t,
-                         out=self.out[:, t, ..., Fh * s:Fh * s + Fh], out_batch_stride=T * H * W * F, out_pixel_stride=F,
+                         out=self.out_tm[t, ..., Fh * s:Fh * s + Fh], out_batch_stride=H * W * F, out_pixel_stride=F,
                          save_gates=False, h_out=self.Hs[s][t + 1], c_out=self.Cs[s][t + 1], gates=self.Gs[s][t],
                          save_layout=self.layout)
         self.t = t + 1
-        return ops.copy_slice(self.step_out, self.out[:, t])
+        return self.out_tm[t]
 
     def record(self):
         """What ``SequenceInput.recorded`` takes once all steps have run."""

@@ -79,6 +79,7 @@ struct Conv32Params {
     const float* bias; // [CH] or null
     void* y;           // [B,H,W,CH] bf16
     int B, H, W, tiles_x, tiles_y, relu;
+    int y_pstride;     // bytes from one output pixel to the next (CH * 2, or more: y is a channel slice of wider pixels)
     const void* mask;      // MASK: [B,H,W,CH] bf16, the output keeps its value where mask > 0 and is zero elsewhere
     float* bias_partial;   // MASK: [grid][32] sums of the kept values per channel
 };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kThreads, (conv32_min_blocks<KS, CH>())) void conv3
 #else
                 if (gy < p.H && gx < p.W) {
 #endif
-                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (CH * 2);
+                    char* dst = static_cast<char*>(p.y) + (((size_t)b * p.H + gy) * p.W + gx) * (size_t)(unsigned)p.y_pstride;
 #pragma unroll
                     for (int c = 0; c < K::SPT; ++c)
                         *reinterpret_cast<u32x4*>(dst + (2 * c + half) * 16) = u32x4{out[c][0], out[c][1], out[c][2], out[c][3]};
@@ -555,12 +556,17 @@ int launch_conv32_wgrad(Conv32WgradParams& p, float* dw, hipStream_t s) {
 }
 
 int conv_same(const char* who, int CH, const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS,
-              int relu, void* y, void* stream) {
+              int relu, void* y, void* stream, long long y_pixel_stride = 0) {
     ISG_REQUIRE(KS == 3 || KS == 5, ISG_EINVAL, "%s: kernel size %d has no instantiation (3, 5)", who, KS);
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "%s: bad shape", who);
     ISG_REQUIRE(x && wimg && y, ISG_EINVAL, "%s: null pointer", who);
+    if (y_pixel_stride == 0) y_pixel_stride = CH;
+    ISG_REQUIRE(y_pixel_stride >= CH && y_pixel_stride % 8 == 0 && y_pixel_stride <= (1 << 20) && (uintptr_t)y % 16 == 0,
+                ISG_EINVAL, "%s: y_pixel_stride %lld (a multiple of 8, at least %d) on a 16-byte aligned y", who,
+                y_pixel_stride, CH);
     Conv32Params p = {};
     p.x = x, p.wimg = wimg, p.bias = bias, p.y = y, p.B = B, p.H = H, p.W = W, p.relu = relu;
+    p.y_pstride = (int)y_pixel_stride * 2;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (CH == 32) return KS == 3 ? launch_conv32<3, 32, false>(p, nullptr, s) : launch_conv32<5, 32, false>(p, nullptr, s);
     return KS == 3 ? launch_conv32<3, 16, false>(p, nullptr, s) : launch_conv32<5, 16, false>(p, nullptr, s);
@@ -572,7 +578,7 @@ int conv_same_masked(const char* who, int CH, const void* x, const void* wimg, c
     ISG_REQUIRE(B >= 1 && H >= 1 && W >= 1, ISG_EINVAL, "%s: bad shape", who);
     ISG_REQUIRE(x && wimg && mask && y && dbias && workspace, ISG_EINVAL, "%s: null pointer", who);
     Conv32Params p = {};
-    p.x = x, p.wimg = wimg, p.y = y, p.B = B, p.H = H, p.W = W;
+    p.x = x, p.wimg = wimg, p.y = y, p.B = B, p.H = H, p.W = W, p.y_pstride = CH * 2;
     p.mask = mask, p.bias_partial = static_cast<float*>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (CH == 32) return KS == 3 ? launch_conv32<3, 32, true>(p, dbias, s) : launch_conv32<5, 32, true>(p, dbias, s);
@@ -601,6 +607,11 @@ extern "C" long long isg_conv32_packed_elems(int KS) {
 extern "C" int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
                           void* y, void* stream) {
     return conv_same("isg_conv32", 32, x, wimg, bias, B, H, W, KS, relu, y, stream);
+}
+
+extern "C" int isg_conv32_strided(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS,
+                                  int relu, void* y, long long y_pixel_stride, void* stream) {
+    return conv_same("isg_conv32_strided", 32, x, wimg, bias, B, H, W, KS, relu, y, stream, y_pixel_stride);
 }
 
 extern "C" long long isg_conv32_masked_workspace_bytes(void) { return (long long)kMaskedMaxBlocks * MROWS * (long long)sizeof(float); }

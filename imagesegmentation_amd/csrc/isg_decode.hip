@@ -458,6 +458,33 @@ __global__ __launch_bounds__(256) void sum_slices_bias_kernel(const float* __res
     for (int s = 0; s < slices; ++s) v += part[(long long)s * n + i];
     out[i] = (T)(v + (float)bias[i % cols]);
 }
+
+// out[row] = x[row][:] . w[:] + bias: a dense layer with ONE output column (a value head).  As a library GEMM it is a
+// matrix-vector product that streams x at a fraction of the memory rate; here one workgroup owns a row, every lane
+// reads 16 bytes of x and of w (which stays in the L2) per trip and keeps float sums, then wave shuffles and LDS.
+__global__ __launch_bounds__(256) void rows_dot_bf16_kernel(const __hip_bfloat16* __restrict__ x,
+                                                            const __hip_bfloat16* __restrict__ w,
+                                                            const __hip_bfloat16* __restrict__ bias, int cols,
+                                                            float* __restrict__ out) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[4];
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)blockIdx.x * cols);
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = threadIdx.x; i < cols / 8; i += 256) {
+        const u32x4 a = __builtin_nontemporal_load(xr + i), b = wr[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (a bf16 is the upper half of its float)
+            acc[k] = __builtin_fmaf(__uint_as_float(a[k] << 16), __uint_as_float(b[k] << 16), acc[k]);
+            acc[k] = __builtin_fmaf(__uint_as_float(a[k] & 0xffff0000u), __uint_as_float(b[k] & 0xffff0000u), acc[k]);
+        }
+    }
+    const float v = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]) + (bias ? (float)bias[0] : 0.0f);
+}
 }  // namespace
 
 namespace {
@@ -677,6 +704,20 @@ extern "C" int isg_sum_slices_bias(const float* part, int slices, int rows, int 
         hipLaunchKernelGGL(sum_slices_bias_kernel<__hip_bfloat16>, grid, block, 0, s, part, slices, n, cols,
                            static_cast<const __hip_bfloat16*>(bias), static_cast<__hip_bfloat16*>(out));
     return isg::check_launch("sum_slices_bias_kernel");
+}
+
+extern "C" int isg_rows_dot(const void* x, const void* w, const void* bias, int rows, int cols, int dtype, float* out,
+                            void* stream) {
+    ISG_REQUIRE(dtype == ISG_BF16, ISG_EDTYPE, "isg_rows_dot: dtype %d (bf16 only)", dtype);
+    ISG_REQUIRE(rows >= 0 && cols >= 8 && cols % 8 == 0, ISG_EINVAL, "isg_rows_dot: rows=%d cols=%d (a multiple of 8)", rows,
+                cols);
+    if (rows == 0) return ISG_OK;
+    ISG_REQUIRE(x && w && out, ISG_EINVAL, "isg_rows_dot: null pointer");
+    ISG_REQUIRE(((uintptr_t)x | (uintptr_t)w) % 16 == 0, ISG_EINVAL, "isg_rows_dot: x and w must be 16-byte aligned");
+    hipLaunchKernelGGL(rows_dot_bf16_kernel, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __hip_bfloat16*>(x), static_cast<const __hip_bfloat16*>(w),
+                       static_cast<const __hip_bfloat16*>(bias), cols, out);
+    return isg::check_launch("rows_dot_bf16_kernel");
 }
 
 extern "C" int isg_sequence_metrics(const int32_t* pred, const int32_t* targets, const int32_t* durations, int B, int T,

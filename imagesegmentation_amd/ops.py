@@ -744,11 +744,30 @@ def pad_channels(x, cout, out=None):
 
 
 @_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])
+def pixel_stride(t):
+    """Elements from one pixel of ``t`` [..., C] to the next when its pixels are evenly spaced in memory in index order
+    (a contiguous tensor: C; a channel slice of a contiguous tensor with wider pixels: that width), else None."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    step = None
+    for size, stride in zip(reversed(t.shape[:-1]), reversed(t.stride()[:-1])):
+        if size == 1:
+            continue
+        if step is None:
+            base = step = stride
+        elif stride != step:
+            return None
+        step = step * size
+    return t.shape[-1] if step is None else base
+
+
 def relu_bwd_bias(dy, y, dbias_out=None):
     """(dz, dbias): dz = dy masked by y > 0 (written over dy when dy is contiguous and owns its memory),
-    dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given)."""
+    dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given).  ``y`` may be a channel slice of
+    wider pixels (``pixel_stride``)."""
     C = y.shape[-1]
-    assert dy.is_contiguous() and y.is_contiguous()
+    ystride = pixel_stride(y)
+    assert dy.is_contiguous() and ystride is not None and ystride >= C and dy.shape == y.shape
     key = (C, str(y.device))
     ws = _bias_ws.get(key)
     if ws is None:
@@ -757,6 +776,12 @@ def relu_bwd_bias(dy, y, dbias_out=None):
     dz = torch.empty_like(dy)
     dbias = torch.empty([C], dtype=torch.float32, device=y.device) if dbias_out is None else dbias_out
     assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == C
+    if ystride != C:
+        rc = _lib.lib().isg_relu_bwd_bias_strided(_lib.ptr(dy), y.data_ptr(), ystride, y.numel() // C, C,
+                                                  dtype_code(y.dtype), _lib.ptr(dz), _lib.ptr(dbias), _lib.ptr(ws),
+                                                  _lib.current_stream())
+        _lib.check(rc, "isg_relu_bwd_bias_strided")
+        return dz, dbias
     rc = _lib.lib().isg_relu_bwd_bias(_lib.ptr(dy), _lib.ptr(y), y.numel() // C, C, dtype_code(y.dtype), _lib.ptr(dz),
                                       _lib.ptr(dbias), _lib.ptr(ws), _lib.current_stream())
     _lib.check(rc, "isg_relu_bwd_bias")
@@ -905,7 +930,14 @@ def conv32(x, wimg, bias, ks, relu, out=None):
     B, H, W, c = x.shape
     assert c in (16, 32) and x.dtype == torch.bfloat16 and x.is_contiguous()
     y = torch.empty_like(x) if out is None else out
-    assert y.shape == x.shape and y.dtype == x.dtype and y.is_contiguous() and y.data_ptr() != x.data_ptr()
+    assert y.shape == x.shape and y.dtype == x.dtype and y.data_ptr() != x.data_ptr()
+    if not y.is_contiguous():  # a 32-channel slice of wider pixels (isg_conv32_strided)
+        ystride = pixel_stride(y)
+        assert c == 32 and ystride is not None and ystride >= c, "out: evenly spaced pixels of 32 channels"
+        rc = _lib.lib().isg_conv32_strided(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)),
+                                           y.data_ptr(), ystride, _lib.current_stream())
+        _lib.check(rc, "isg_conv32_strided")
+        return y
     fn = _lib.lib().isg_conv32 if c == 32 else _lib.lib().isg_conv16
     rc = fn(_lib.ptr(x), _lib.ptr(wimg), _lib.ptr(bias), B, H, W, int(ks), int(bool(relu)), _lib.ptr(y),
             _lib.current_stream())

@@ -170,11 +170,12 @@ def _dense_init(shape, device, gen):
     return (torch.rand(shape, device=device, generator=gen) * 2 - 1) * limit
 
 
-def _dense_rows(flat, w, b, slices=16):
+def _dense_rows(flat, w, b, slices=16, b32=None):
     """flat [M, K] @ w [K, N] + b as float32, operands in the compute type.  An acting step has few rows and a long
     reduction axis (1024 x 32768 x 1024: 32 output tiles of a library GEMM for 256 CUs): the reduction axis is cut
     into ``slices`` batched GEMMs with float32 results that are then summed (0.18 -> 0.08 ms, and the partial sums
-    are never rounded to bf16)."""
+    are never rounded to bf16; with ``b32``, the float32 bias, sum and bias are one launch).  One output column (the
+    value head) is a row-wise dot product instead (isg_rows_dot)."""
     M, K = flat.shape
     N = w.shape[1]
     if (not os.environ.get("ISG_NO_SPLIT_HEAD") and flat.is_cuda and flat.dtype == torch.bfloat16 and flat.is_contiguous() and w.is_contiguous() and N >= 64 and
@@ -182,9 +183,15 @@ def _dense_rows(flat, w, b, slices=16):
         try:
             part = torch.bmm(flat.view(M, slices, K // slices).transpose(0, 1), w.view(slices, K // slices, N),
                              out_dtype=torch.float32)
+            if b32 is not None and b32.dtype == torch.float32:  # (the float32 master bias: one launch)
+                return decode.sum_slices_bias(part, b32)
             return part.sum(0).add_(b)
         except TypeError:  # (a torch without float32 results from a bf16 batched GEMM)
             pass
+    if N == 1 and not os.environ.get("ISG_NO_SPLIT_HEAD"):  # one column: a row-wise dot product, not a GEMM
+        v = decode.rows_dot(flat, w, b)
+        if v is not None:
+            return v[:, None]
     return torch.addmm(b, flat, w).float()
 
 
@@ -307,6 +314,11 @@ class LSTMPolicy:
             seq = SequenceInput(x_seq=feats.transpose(0, 1))
         seq.recorded = recorded
         out, final = dynamic_rnn(self.lstm, seq, initial_state=LSTMStateTuple(*state), time_major=False)
+        if T > 1 and N > 1 and out.transpose(0, 1).is_contiguous():
+            # an adopted pass keeps its outputs time-major: the heads take the rows in that order (no copy into
+            # batch-major order) and the results go out as [N, T] views of time-major memory
+            logits, vf = self._heads(out.transpose(0, 1).reshape(T * N, -1))
+            return logits.view(T, N, -1).transpose(0, 1), vf.view(T, N).transpose(0, 1), final
         logits, vf = self._heads(out.reshape(N * T, -1))
         return logits.reshape(N, T, -1), vf.reshape(N, T), final
 
@@ -321,7 +333,7 @@ class LSTMPolicy:
                 out.append(_DenseHead.apply(flat, w, b, cache).float())
             elif dt != w.dtype:
                 wc, bc = _head_weights(dt, w, b, cache)
-                out.append(_dense_rows(flat, wc, bc))
+                out.append(_dense_rows(flat, wc, bc, b32=b.detach()))
             else:
                 out.append(torch.addmm(b.detach(), flat, w.detach()))
         return out[0], out[1][:, 0]
@@ -447,9 +459,11 @@ class A3C:
                    env.history_points, env.done)
         where = tuple(t.data_ptr() for t in tensors) + (N, T, P)
         if r is None or r["where"] != where:
+            rec = pi.recorder(N, T) if self.reuse_forward else pi.stepper(N)
             r = self._rollout = dict(
-                where=where, graph=None, rec=pi.recorder(N, T) if self.reuse_forward else pi.stepper(N),
-                enc=self._encoder_buffers(state, N, T) if self.reuse_forward and self.reuse_encoder else None, offset=torch.zeros([], dtype=torch.int64, device=dev),
+                where=where, graph=None, rec=rec,
+                enc=self._encoder_buffers(state, N, T, rec) if self.reuse_forward and self.reuse_encoder else None,
+                offset=torch.zeros([], dtype=torch.int64, device=dev),
                 obs=torch.zeros((N, T) + tuple(state.shape[1:]), dtype=state.dtype, device=dev),
                 xy=torch.zeros([N, T, 2], dtype=torch.int32, device=dev),
                 actions=torch.zeros([N, T], dtype=torch.int64, device=dev),
@@ -505,7 +519,7 @@ class A3C:
                     terminal=env.done.clone(), forward=r["rec"].record() if self.reuse_forward else None,
                     encoder=r["enc"] if self.reuse_forward and self.reuse_encoder else None)
 
-    def _encoder_buffers(self, state, N, T):
+    def _encoder_buffers(self, state, N, T, rec=None):
         """Where the acting steps keep the encoder's padded input and layer outputs for the update, time-major
         [T, N, H, W, 32] each; None where the encoder does not run on the kernels that can keep them."""
         pi = self.local_network
@@ -513,7 +527,13 @@ class A3C:
             return None
         shape = [T, N] + list(state.shape[1:3]) + [int(pi.convs[0][0].shape[3])]
         new = lambda: torch.empty(shape, dtype=torch.bfloat16, device=state.device)
-        return new(), [new() for _ in pi.convs]
+        ys = [new() for _ in pi.convs]
+        if rec is not None and not os.environ.get("ISG_NO_INPUT_SLOTS"):
+            # the top layer writes its features where the recurrent cell reads them: no copy per acting step
+            slots = rec.input_slots()
+            if slots.dtype == torch.bfloat16 and list(slots.shape) == shape and shape[-1] == 32:
+                ys[-1] = slots
+        return new(), ys
 
     def process(self, images=None, polygons=None, device_batch=None):
         with self.derived:
@@ -532,8 +552,12 @@ class A3C:
         # (the weights have not changed since the rollout: the update adopts its pass of the recurrence)
         logits, vf, _ = pi.forward(batch["si"], pi.get_initial_features(N), recorded=batch.get("forward"),
                                    recorded_encoder=batch.get("encoder"))
-        loss, parts = a3c_loss(logits.reshape(N * T, -1), vf.reshape(-1), batch["a"].reshape(-1), adv.reshape(-1),
-                               r.reshape(-1), live.reshape(-1))
+        # (the loss is a sum over rows: they go in the order the logits are stored in, time-major after an adopted pass)
+        if T > 1 and N > 1 and logits.transpose(0, 1).is_contiguous():
+            rows = lambda a: a.transpose(0, 1).reshape((N * T,) + tuple(a.shape[2:]))
+        else:
+            rows = lambda a: a.reshape((N * T,) + tuple(a.shape[2:]))
+        loss, parts = a3c_loss(rows(logits), rows(vf), rows(batch["a"]), rows(adv), rows(r), rows(live))
         (loss / N).backward()
         norm = self.opt.step()
         # one device-to-host copy for all the scalars of the update

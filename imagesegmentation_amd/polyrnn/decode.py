@@ -225,10 +225,32 @@ def dense_few_rows(flat, w, b, slices=None):
                          out_dtype=torch.float32)
     except TypeError:  # (a torch without float32 results from a bf16 batched GEMM)
         return None
-    out = torch.empty([M, N], dtype=flat.dtype, device=flat.device)
+    return sum_slices_bias(part, b)
+
+
+def sum_slices_bias(part, b):
+    """part float32 [slices, M, N] summed over the slices + b [N], in b's type (float32 or bf16), in one launch."""
+    slices, M, N = part.shape
+    assert part.dtype == torch.float32 and part.is_contiguous() and b.numel() == N
+    out = torch.empty([M, N], dtype=b.dtype, device=part.device)
     rc = _lib.lib().isg_sum_slices_bias(_lib.ptr(part), slices, M, N, _lib.ptr(b.contiguous()), dtype_code(out.dtype),
                                         _lib.ptr(out), _lib.current_stream())
     _lib.check(rc, "isg_sum_slices_bias")
+    return out
+
+
+def rows_dot(flat, w, b=None):
+    """flat [M, K] . w [K] (or [K, 1]) + b as float32 [M], operands bf16 (isg_rows_dot): a dense layer with one output
+    column.  None when the operands do not fit (the caller's library GEMM then)."""
+    M, K = flat.shape
+    if not (flat.is_cuda and flat.dtype == torch.bfloat16 and w.dtype == flat.dtype and flat.is_contiguous() and
+            w.is_contiguous() and w.numel() == K and K % 8 == 0 and (b is None or b.dtype == flat.dtype) and
+            flat.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
+        return None
+    out = torch.empty([M], dtype=torch.float32, device=flat.device)
+    rc = _lib.lib().isg_rows_dot(_lib.ptr(flat), _lib.ptr(w), _lib.ptr(b), M, K, dtype_code(flat.dtype), _lib.ptr(out),
+                                 _lib.current_stream())
+    _lib.check(rc, "isg_rows_dot")
     return out
 
 

@@ -378,6 +378,12 @@ int isg_decode_polygons(const int32_t* predicted, const int32_t* durations, cons
 int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype, void* out,
                         void* stream);
 
+/* out float [rows] = x [rows][cols] . w [cols] + bias[0] (bias may be NULL), x, w and bias bf16: a dense layer with one
+ * output column - the value head of polyrl/a3c/model.py:39 at an acting step, which as a library GEMM is a
+ * matrix-vector product far below the memory rate.  cols a multiple of 8; x and w 16-byte aligned. */
+int isg_rows_dot(const void* x, const void* w, const void* bias, int rows, int cols, int dtype, float* out,
+                 void* stream);
+
 /* One iteration of the reference's autoregressive decode loop (polyrnn/Model.py:231-249; end-token variant
  * polyrnn/EndTokenExperiment.py:158-170, EndTokenDeepExperiment_2.py:150-170) for every sample, in one launch
  * after the head, with no host round trip.  Per row r of logits [rows][cols]:
@@ -454,6 +460,10 @@ int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, voi
 long long isg_relu_bwd_bias_workspace_bytes(int C);
 int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                       void* workspace, void* stream);
+/* isg_relu_bwd_bias with y as a C-channel slice of wider pixels, y_pixel_stride elements apart (a multiple of the
+ * vector width, at least C): the backward of a layer whose output was written by isg_conv32_strided. */
+int isg_relu_bwd_bias_strided(const void* dy, const void* y, long long y_pixel_stride, long long n, int C, int dtype,
+                              void* dz, float* dbias, void* workspace, void* stream);
 /* isg_relu_bwd_bias without the workspace argument and without any allocation: the per-workgroup partial
  * sums live in an array built into the library (256 KiB per GPU, held until the process ends), whose
  * address is looked up on the first call on each device.  No counterpart in the reference; it is for
@@ -526,6 +536,11 @@ int isg_conv32_pack(const float* w, int KS, int C, int data_gradient, void* wimg
 int isg_conv32_pack_padded(const float* w, int KS, int C, int cin, void* wimg, void* stream);
 int isg_conv32(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu, void* y,
                void* stream);
+/* isg_conv32 whose output pixels lie y_pixel_stride elements apart (a multiple of 8, at least 32): y is a
+ * 32-channel slice of wider pixels - the encoder's top layer writing its features straight into the joint
+ * [features | h] input of the recurrent cell (reference polyrl/a3c/model.py:19-23) instead of being copied there. */
+int isg_conv32_strided(const void* x, const void* wimg, const float* bias, int B, int H, int W, int KS, int relu,
+                       void* y, long long y_pixel_stride, void* stream);
 long long isg_conv32_wgrad_workspace_bytes(int KS);
 int isg_conv32_wgrad(const void* x, const void* dz, int B, int H, int W, int KS, void* workspace, float* dw,
                      void* stream);

@@ -436,6 +436,26 @@ def test_column_sums_against_float64(rows, cols, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,bias", [(1, 8, False), (5, 1000, True), (300, 32768, True)])
+def test_one_column_dense_layer_against_float64(rows, cols, bias):
+    """isg_rows_dot (a value head: one output column) against the float64 product of the same bf16 operands, and
+    the float32 bias-less GEMM's answer for good measure; shapes it does not take answer None."""
+    from imagesegmentation_amd.polyrnn import decode
+    g = torch.Generator(device="cuda:0").manual_seed(rows * 7 + cols)
+    x = torch.randn([rows, cols], device="cuda:0", generator=g).bfloat16()
+    w = (torch.randn([cols, 1], device="cuda:0", generator=g) * 0.05).bfloat16()
+    b = torch.randn([1], device="cuda:0", generator=g).bfloat16() if bias else None
+    got = decode.rows_dot(x, w, b)
+    assert got is not None and got.dtype == torch.float32 and tuple(got.shape) == (rows,)
+    ref = (x.double() @ w.double())[:, 0] + (b.double() if bias else 0.0)
+    scale = float((x.double().abs() @ w.double().abs()).max())
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * max(1.0, scale)
+    assert torch.equal(got, decode.rows_dot(x, w, b))
+    assert decode.rows_dot(x.float(), w.float(), None) is None
+    assert decode.rows_dot(x[:, :cols - 4].contiguous(), w[:cols - 4].contiguous(), None) is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("end_token", [False, True])
 def test_update_that_adopts_the_rollouts_forward_pass_equals_the_update_that_runs_its_own(end_token):
     """BatchedReinforce.step with the recurrence of the rollout kept for the update (SequenceRecorder) against the

@@ -327,6 +327,34 @@ def test_encoder_square_convolution_kernels_against_float64_conv(KS, C):
     assert rel_err(dw, ref_dw) < 1e-4  # float accumulation of exact bf16 products
 
 
+@pytest.mark.parametrize("KS", [3, 5])
+def test_convolution_into_a_channel_slice_of_wider_pixels(KS):
+    """isg_conv32_strided / isg_relu_bwd_bias_strided: the layer's output written as the first 32 channels of
+    48-channel pixels (the joint input of a recurrent cell) equals the contiguous output bit for bit, leaves the
+    other channels alone, and the ReLU backward reads it there with the same result."""
+    from imagesegmentation_amd import ops
+    rs = np.random.RandomState(KS)
+    T, B, H, W, C = 2, 2, 19, 37, 32
+    dev = "cuda:0"
+    bf = lambda a: torch.tensor(a, device=dev).to(torch.bfloat16)
+    tw = torch.tensor(rs.randn(KS, KS, C, C) * 0.05, dtype=torch.float32, device=dev)
+    tb = torch.tensor(rs.randn(C) * 0.1, dtype=torch.float32, device=dev)
+    x = bf(rs.randn(T * B, H, W, C))
+    want = ops.conv32(x, ops.conv32_pack(tw), tb, KS, relu=True)
+    wide = torch.full([T, B, H, W, 48], 7.0, dtype=torch.bfloat16, device=dev)
+    slots = wide[..., :C]
+    assert ops.pixel_stride(slots) == 48 and ops.pixel_stride(slots[1]) == 48 and ops.pixel_stride(wide[:, 0]) is None
+    for t in range(T):
+        got = ops.conv32(x[t * B:(t + 1) * B], ops.conv32_pack(tw), tb, KS, relu=True, out=slots[t])
+        assert got.data_ptr() == slots[t].data_ptr()
+    assert torch.equal(slots.reshape(T * B, H, W, C), want)
+    assert bool((wide[..., C:] == 7.0).all())
+    dy = bf(rs.randn(T * B, H, W, C))
+    dz0, db0 = ops.relu_bwd_bias(dy.clone(), want)
+    dz1, db1 = ops.relu_bwd_bias(dy.clone(), slots.view(T * B, H, W, C))
+    assert torch.equal(dz0, dz1) and torch.equal(db0, db1)
+
+
 @pytest.mark.parametrize("C", [32, 16])
 @pytest.mark.parametrize("KS", [3, 5])
 def test_masked_data_gradient_equals_data_gradient_then_relu_backward(KS, C):
