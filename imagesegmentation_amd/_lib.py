@@ -72,6 +72,7 @@ SIGNATURES = {
     "isg_copy_channel_slice": (_int, [_vp, _vp, _vp, _vp, _int, _ll, _ll, _ll, _vp]),
     "isg_a3c_loss_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_a3c_loss_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "isg_rollout_record": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "isg_gae": (_int, [_vp, _vp, _vp, _vp, _int, _int, _f64, _f64, _vp, _vp, _vp]),
     "isg_column_sums_workspace_bytes": (_ll, [_int]),
     "isg_column_sums": (_int, [_vp, _ll, _int, _int, _vp, _vp, _vp]),

@@ -202,6 +202,35 @@ extern "C" int isg_gae(const double* rewards, const float* values, const int32_t
     return isg::check_launch("gae_kernel");
 }
 
+namespace {
+// one thread per environment: the step's entries of a rollout's record.  An environment ended at THIS step when it is
+// done and its length - the count of steps it took while running - is t + 1.
+__global__ __launch_bounds__(256) void rollout_record_kernel(const uint8_t* __restrict__ done,
+                                                             const int32_t* __restrict__ lengths,
+                                                             const int32_t* __restrict__ inter,
+                                                             const int32_t* __restrict__ uni,
+                                                             const float* __restrict__ step_values, int n, int T, int t,
+                                                             double* __restrict__ rewards, float* __restrict__ values) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const bool terminal = done[e] != 0 && lengths[e] == t + 1;
+    rewards[(size_t)e * T + t] = terminal ? (double)inter[e] / (double)uni[e] : 0.0;
+    if (values) values[(size_t)e * T + t] = step_values[e];
+}
+}  // namespace
+
+extern "C" int isg_rollout_record(const uint8_t* done, const int32_t* lengths, const int32_t* inter, const int32_t* uni,
+                                  const float* step_values, int n, int T, int t, double* rewards, float* values,
+                                  void* stream) {
+    ISG_REQUIRE(n >= 0 && T >= 1 && t >= 0 && t < T, ISG_EINVAL, "isg_rollout_record: n=%d, slot %d outside [0, %d)", n, t, T);
+    if (n == 0) return ISG_OK;
+    ISG_REQUIRE(done && lengths && inter && uni && rewards && ((values == nullptr) == (step_values == nullptr)),
+                ISG_EINVAL, "isg_rollout_record: null pointer (values and step_values go together)");
+    hipLaunchKernelGGL(rollout_record_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), done,
+                       lengths, inter, uni, step_values, n, T, t, rewards, values);
+    return isg::check_launch("rollout_record_kernel");
+}
+
 extern "C" int isg_history_frames(const int32_t* points, int n, int size, int hist, int dtype, void* out,
                                   int out_channels, int out_offset, void* stream) {
     ISG_REQUIRE(n >= 0 && size >= 1 && hist >= 0, ISG_EINVAL, "isg_history_frames: bad sizes");

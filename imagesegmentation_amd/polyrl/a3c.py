@@ -475,11 +475,16 @@ class A3C:
             r["rec"].reset()
             r["lengths"].zero_()
             state = env._state
+            fold = not os.environ.get("ISG_NO_ROLLOUT_RECORD")  # (the switch: the tensor-operation form, for A/B runs)
             for t in range(T):
-                active = ~env.done
                 r["obs"][:, t] = state
                 keep = None if r["enc"] is None else (r["enc"][0][t], [y[t] for y in r["enc"][1]])
                 xy, v = pi.act_step_xy(state, r["rec"], r["offset"], P, keep=keep)
+                if fold and v.dtype == torch.float32 and v.is_contiguous():
+                    # action, length, reward and value of the step filed by the environment's own launches
+                    state = env.step_recorded(xy, t, r["xy"], r["lengths"], r["rewards"], v, r["values"])
+                    continue
+                active = ~env.done
                 r["xy"][:, t], r["values"][:, t] = xy, v
                 r["lengths"] += active.to(torch.int32)
                 state, reward, _ = env.step(xy, host_sync=False)

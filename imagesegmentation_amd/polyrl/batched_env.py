@@ -152,7 +152,7 @@ class BatchedPolygonEnv:
         if record is not None:
             rec_p, rec_a, rec_l = record
             T = rec_a.shape[1]
-            assert rec_p.is_contiguous() and rec_a.is_contiguous() and rec_l.is_contiguous()
+            assert (rec_p is None or rec_p.is_contiguous()) and rec_a.is_contiguous() and rec_l.is_contiguous()
         rc = _lib.lib().isg_env_step(_lib.ptr(actions), _lib.ptr(self.vertices), self.vcap * 2,
                                      _lib.ptr(self.predicted_vertices), self.vcap, _lib.ptr(self.num_predicted),
                                      _lib.ptr(self.history_points), self.hist, _lib.ptr(self.done), n, self.size,
@@ -194,6 +194,32 @@ class BatchedPolygonEnv:
                                                self.num_vertices[idx].contiguous(), self.size)
                 reward[idx] = inter.double() / union.double()
         return self._state, reward, self.done.clone()
+
+    def step_recorded(self, actions, t, rec_actions, rec_lengths, rec_rewards, step_values=None, rec_values=None,
+                      render=True):
+        """``step(host_sync=False)`` for a rollout that files its record on the device, in four launches (environment
+        step, history frames, IoU, record) and without the tensor operations between them: slot ``t`` of
+        ``rec_actions`` int32 [N, T, 2] gets the action, ``rec_lengths`` int32 [N] - zero at the rollout's first
+        step - counts the steps an environment took while running, ``rec_rewards`` float64 [N, T] gets the IoU where
+        the environment ended at this step and 0 elsewhere, ``rec_values`` float32 [N, T] the ``step_values`` [N].
+        Returns the next state."""
+        n = self.num_envs
+        self.advance(actions, (None, rec_actions, rec_lengths), t)
+        if render and self.hist > 0:
+            self._render_history()
+        inter, union = util.raster_iou(self.predicted_vertices, self.num_predicted, self.vertices, self.num_vertices,
+                                       self.size)
+        T = rec_actions.shape[1]
+        assert rec_rewards.dtype == torch.float64 and rec_rewards.is_contiguous() and tuple(rec_rewards.shape) == (n, T)
+        assert rec_lengths.dtype == torch.int32
+        if rec_values is not None:
+            assert rec_values.dtype == torch.float32 and rec_values.is_contiguous() and tuple(rec_values.shape) == (n, T)
+            assert step_values.dtype == torch.float32 and step_values.is_contiguous() and step_values.numel() == n
+        rc = _lib.lib().isg_rollout_record(_lib.ptr(self.done), _lib.ptr(rec_lengths), _lib.ptr(inter), _lib.ptr(union),
+                                           _lib.ptr(step_values) if rec_values is not None else None, n, T, int(t),
+                                           _lib.ptr(rec_rewards), _lib.ptr(rec_values), _lib.current_stream())
+        _lib.check(rc, "isg_rollout_record")
+        return self._state
 
     def terminal_rewards(self):
         """IoU of every environment's predicted polygon against its true one, in one launch:

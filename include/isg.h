@@ -118,6 +118,14 @@ int isg_env_step(const int32_t* actions, const int32_t* true_vertices, int true_
 int isg_gae(const double* rewards, const float* values, const int32_t* lengths, const double* bootstrap, int N, int T,
             double gamma, double lambda, double* advantages, double* returns, void* stream);
 
+/* Slot t of a rollout's record after isg_env_step (with rec_lengths) and the IoU launch of that step (reference
+ * polyrl/polygon_env.py:33-46 pays the IoU at the terminal step, polyrl/a3c/a3c.py:122-147 files reward and value):
+ * rewards double [n][T] at [e][t] = inter[e] / union[e] (in double) where environment e ended at this step - done[e]
+ * and lengths[e] == t + 1, lengths counting from 0 at the rollout's first step - else 0; values float [n][T] at
+ * [e][t] = step_values[e] (both NULL: no values kept). */
+int isg_rollout_record(const uint8_t* done, const int32_t* lengths, const int32_t* inter, const int32_t* uni,
+                       const float* step_values, int n, int T, int t, double* rewards, float* values, void* stream);
+
 /* ---- ConvLSTM cell ------------------------------------------------------------------------
  * One step of the reference cell (reference convLSTM.py:26-45):
  *     y = conv(h_prev, W_h, SAME) + conv(x, W_x, SAME) + b ;  j, i, f, o = split(y, 4)
