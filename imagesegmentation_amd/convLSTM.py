@@ -600,9 +600,13 @@ class WideRecorder:
         self.groups = _wide_groups(cell, C)
         cs = self.groups[0][1].cs
         self.layout = ops.SAVE_FACTORS if ops.bwd_fused_supported(self.groups[0][1], B, H, W) else ops.SAVE_GATES
-        self.xw = torch.zeros([T, B, H, W, cs], dtype=dt, device=device)
+        # (one slot more than steps: a further group's h is written where the NEXT step reads it, inside that step's
+        # joint input - also after the last step - and the backward sweep reads it there; the h slots of step 0 are
+        # the zero state and are never written)
+        self.xw = torch.zeros([T + 1, B, H, W, cs], dtype=dt, device=device)
         self.Hs = [[torch.zeros([B, H, W, Fh], dtype=dt, device=device)] +
-                   list(torch.empty([T, B, H, W, Fh], dtype=dt, device=device).unbind(0)) for _ in range(k)]
+                   list(torch.empty([T, B, H, W, Fh], dtype=dt, device=device).unbind(0))] + \
+                  [[self.xw[t, ..., C + Fh * (s - 1):C + Fh * s] for t in range(T + 1)] for s in range(1, k)]
         self.Cs = [[torch.zeros([B, H, W, Fh], dtype=torch.float32, device=device)] +
                    list(torch.empty([T, B, H, W, Fh], dtype=torch.float32, device=device).unbind(0)) for _ in range(k)]
         self.Gs = [torch.empty([T] + ops.saved_shape(B, H, W, Fh, self.layout), dtype=dt, device=device)
@@ -622,7 +626,7 @@ class WideRecorder:
         """[T, B, H, W, C]: where the steps' inputs live, the first C channels of the joint input's wider pixels.  A
         producer that can write pixels that far apart (``ops.conv32(out=)``) fills ``input_slots()[t]`` itself and hands
         that very view to ``step``, which then copies nothing."""
-        return self.xw[..., :self.C]
+        return self.xw[:self.T, ..., :self.C]
 
     def step(self, x):
         """x [B, H, W, C] -> the cell's output h [B, H, W, F] of this step (its block of the kept outputs)."""
@@ -635,13 +639,11 @@ class WideRecorder:
         slot = xw[..., :C]
         if not (x.data_ptr() == slot.data_ptr() and x.stride() == slot.stride() and x.dtype == xw.dtype):
             ops.copy_slice(slot, x if x.dtype == xw.dtype else x.to(xw.dtype))  # (else: written in place, ``input_slots``)
-        for s in range(1, self.k):
-            ops.copy_slice(xw[..., C + Fh * (s - 1):C + Fh * s], self.Hs[s][t])
         for s in range(self.k):
             ops.cell_fwd(xw, self.Hs[0][t], self.Cs[s][t], groups[s][1], None, t,
                          out=self.out_tm[t, ..., Fh * s:Fh * s + Fh], out_batch_stride=H * W * F, out_pixel_stride=F,
-                         save_gates=False, h_out=self.Hs[s][t + 1], c_out=self.Cs[s][t + 1], gates=self.Gs[s][t],
-                         save_layout=self.layout)
+                         save_gates=False, h_out=self.Hs[s][t + 1], h_pixel_stride=Fh if s == 0 else xw.shape[-1],
+                         c_out=self.Cs[s][t + 1], gates=self.Gs[s][t], save_layout=self.layout)
         self.t = t + 1
         return self.out_tm[t]
 
@@ -649,7 +651,7 @@ class WideRecorder:
         """What ``SequenceInput.recorded`` takes once all steps have run."""
         if self.t != self.T:
             raise RuntimeError("the recorder ran %d of its %d steps" % (self.t, self.T))
-        return (self.xw, self.Hs, self.Cs, self.Gs, _wide_groups(self.cell, self.C), self.layout, self.out)
+        return (self.xw[:self.T], self.Hs, self.Cs, self.Gs, _wide_groups(self.cell, self.C), self.layout, self.out)
 
 
 class _SequenceFunction(torch.autograd.Function):
@@ -944,6 +946,9 @@ class _WideSequenceFunction(torch.autograd.Function):
         # one launch per (step, group) where the fused backward step exists for the groups' shape (its carried
         # cell-state gradient is in the compute type and ping-pongs between two buffers), else three
         fused = t_run > 0 and layout == ops.SAVE_FACTORS
+        # (an initial state that takes no gradient - the zero state of a rollout: nothing is joined for it after the
+        # first step's launches)
+        need_state = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
         dc_state = [part(d_c, s, dt if fused else torch.float32) for s in range(k)]
         dh_state = [part(d_h, s, dt) for s in range(k)]
         if fused:
@@ -1003,12 +1008,16 @@ class _WideSequenceFunction(torch.autograd.Function):
                     dh0_sum = dh_extra if dh0_sum is None else dh0_sum + dh_extra
             if fused:
                 dh_state[0], dh_next0 = dh_next0, dh_state[0]
+            if t == 0 and not need_state:
+                break
             if dh0_sum is not None:
                 dh_state[0] += dh0_sum
             for s in range(1, k):  # h_prev[16 s:] entered through the joint input
                 g = dxw[..., C + Fh * (s - 1):C + Fh * s]
                 if live is not None:
                     dh_state[s] = torch.where(live, g, dh_state[s]).contiguous()
+                elif fused and not os.environ.get("ISG_NO_STRIDED_BWD"):
+                    dh_state[s] = g  # (the fused step reads it in place, as a slice of the wider pixels)
                 else:
                     dh_state[s] = ops.copy_slice(torch.empty([B, H, W, Fh], dtype=dt, device=dev), g)
         dw_x = torch.zeros_like(cell.input_to_state_kernel, dtype=torch.float32)
@@ -1028,8 +1037,8 @@ class _WideSequenceFunction(torch.autograd.Function):
             d_x = ops.copy_slice(torch.empty([B, T, H, W, C], dtype=dt, device=dev).transpose(0, 1), d_xw[..., :C])
         else:
             d_x = ops.copy_slice(torch.empty([T, B, H, W, C], dtype=dt, device=dev), d_xw[..., :C])
-        return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd), torch.cat(dh_state, dim=-1).to(hd),
-                dw_x, dw_h, dbias, None)
+        return (None, None, None, d_x.to(xd), torch.cat(dc_state, dim=-1).to(cd) if need_state else None,
+                torch.cat(dh_state, dim=-1).to(hd) if need_state else None, dw_x, dw_h, dbias, None)
 
 
 def _dynamic_rnn_wide(multi, seq, durations_dev, t_run, initial_state):

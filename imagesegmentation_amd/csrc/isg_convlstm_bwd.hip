@@ -58,6 +58,8 @@ struct BwdParams {
     const float* c_prev;    // [B,H,W,F] float, or bf16 when cprev_bf16
     int cprev_bf16;
     const void* h_cur;      // [B,H,W,F]: this step's new h
+    int h_cur_pstride;      // C0 == 48 only: bytes from pixel to pixel of h_cur and of dh_state (32, or more: 16-channel
+    int dh_state_pstride;   // slices of wider pixels - the other group's slot of the joint input and of its gradient)
     const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
     long long dh_above_bstride;
     int pool_shift;         // > 0: dh_above lives on the grid pooled by 2^s x 2^s windows (average pool)
@@ -246,6 +248,10 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     unsigned pw_inside = 0u, x_inside = 0u;
     int st_dur = 0x7fffffff;
     int st_hp[4] = {-1, 0, -1, 0};
+    // (only the 48-channel kernel - two groups of a wider cell sharing one joint input - meets h and its carried
+    // gradient as slices of wider pixels; the others keep the constant)
+    const unsigned hc_stride = C0 == 48 ? (unsigned)p.h_cur_pstride : 32u;
+    const unsigned ds_stride = C0 == 48 ? (unsigned)p.dh_state_pstride : 32u;
 
     struct Tile {
         int b, ty0, tx0;
@@ -301,14 +307,14 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
             if constexpr (zero_state) scp[j] = make_uint4(0u, 0u, 0u, 0u);
             else scp[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.c_prev) + (size_t)(pixel * 64u + q * 16u));
         }
-        shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * 32u + q * 8u));
+        shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * hc_stride + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
                                                  (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
         if constexpr (no_carry) {
             sds[j] = sdc[j] = make_uint2(0u, 0u);
         } else {
-            sds[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * 32u + q * 8u));
+            sds[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_state) + (size_t)(pixel * ds_stride + q * 8u));
             sdc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dc_state) + (size_t)(pixel * 32u + q * 8u));
         }
     };
@@ -547,7 +553,8 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
                         *reinterpret_cast<unsigned*>(static_cast<char*>(p.dc_prev) + so) =
                             no_carry ? 0u : *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dc_state) + so);
                         *reinterpret_cast<unsigned*>(static_cast<char*>(p.dh_prev) + so) =
-                            no_carry ? 0u : *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) + so);
+                            no_carry ? 0u : *reinterpret_cast<const unsigned*>(static_cast<const char*>(p.dh_state) +
+                                                                               (size_t)(pixel * ds_stride + qq * 4u));
                     }
                     if (p.dx && !p.dx_accumulate)
                         for (int ch = 2 * qq; ch < p.dx_channels; ch += 16)
@@ -1126,14 +1133,20 @@ extern "C" long long isg_convlstm_bwd_fused_hist_bytes(int B, int hist) {
     return hist_dy_bytes(B, hist) + (long long)kHistGroups * 9 * hist * NG * 4;
 }
 
-extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev_v, const void* h_cur, const void* dh_above,
-                                      long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
-                                      const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
-                                      int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
-                                      int t, const int32_t* hist_points, int hist, long long hist_batch_stride,
-                                      void* hist_scratch, void* dc_prev, void* dh_prev, void* dx, int dx_channels,
-                                      int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
-                                      void* stream) {
+namespace {
+int bwd_fused_impl(const void* gates, const void* c_prev_v, const void* h_cur, const void* dh_above,
+                   long long dh_above_batch_stride, int dh_above_pool, const void* dh_state, const void* dc_state,
+                   const void* x, const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs, int F,
+                   int dtype, const int32_t* durations, int t, const int32_t* hist_points, int hist,
+                   long long hist_batch_stride, void* hist_scratch, void* dc_prev, void* dh_prev, void* dx,
+                   int dx_channels, int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
+                   void* stream, int h_cur_pixel_stride, int dh_state_pixel_stride) {
+    ISG_REQUIRE(h_cur_pixel_stride >= F_ && h_cur_pixel_stride <= 64 && h_cur_pixel_stride % 8 == 0 &&
+                    dh_state_pixel_stride >= F_ && dh_state_pixel_stride <= 64 && dh_state_pixel_stride % 8 == 0 &&
+                    (Cs == 48 || (h_cur_pixel_stride == F_ && dh_state_pixel_stride == F_)),
+                ISG_EINVAL,
+                "isg_convlstm_bwd_fused: pixel strides of h_cur / dh_state (%d, %d): multiples of 8 in [16, 64], and 16 "
+                "unless Cs = 48", h_cur_pixel_stride, dh_state_pixel_stride);
     // (ISG_HIST_DEFER: the caller zeroes the history scratch once and folds it once, see isg_convlstm_bwd_fused_hist_finish)
     const bool hist_defer = (mode & ISG_HIST_DEFER) != 0;
     const bool cprev_bf16 = (mode & ISG_CPREV_BF16) != 0;
@@ -1171,6 +1184,7 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev_v, c
     const int MT = (Cs + F_ + 31) / 32;
     BwdParams p = {};
     p.gates = gates, p.c_prev = c_prev, p.cprev_bf16 = cprev_bf16 ? 1 : 0, p.h_cur = h_cur;
+    p.h_cur_pstride = h_cur_pixel_stride * 2, p.dh_state_pstride = dh_state_pixel_stride * 2;
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
     p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
     p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;
@@ -1211,6 +1225,35 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev_v, c
         rc = isg::check_launch("hist_side_finish_kernel");
     }
     return rc;
+}
+}  // namespace
+
+extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev, const void* h_cur, const void* dh_above,
+                                      long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                                      const void* dc_state, const void* x, const void* h_prev, const void* packed_dgrad,
+                                      int B, int H, int W, int C, int Cs, int F, int dtype, const int32_t* durations,
+                                      int t, const int32_t* hist_points, int hist, long long hist_batch_stride,
+                                      void* hist_scratch, void* dc_prev, void* dh_prev, void* dx, int dx_channels,
+                                      int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
+                                      void* stream) {
+    return bwd_fused_impl(gates, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_above_pool, dh_state, dc_state, x,
+                          h_prev, packed_dgrad, B, H, W, C, Cs, F, dtype, durations, t, hist_points, hist,
+                          hist_batch_stride, hist_scratch, dc_prev, dh_prev, dx, dx_channels, dx_channel_stride,
+                          dx_accumulate, workspace, mode, dw_x, stream, F_, F_);
+}
+
+extern "C" int isg_convlstm_bwd_fused_strided(const void* gates, const void* c_prev, const void* h_cur,
+                                              int h_cur_pixel_stride, const void* dh_above,
+                                              long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                                              int dh_state_pixel_stride, const void* dc_state, const void* x,
+                                              const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C,
+                                              int Cs, int F, int dtype, const int32_t* durations, int t, void* dc_prev,
+                                              void* dh_prev, void* dx, int dx_channels, int dx_channel_stride,
+                                              int dx_accumulate, void* workspace, int mode, void* stream) {
+    return bwd_fused_impl(gates, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_above_pool, dh_state, dc_state, x,
+                          h_prev, packed_dgrad, B, H, W, C, Cs, F, dtype, durations, t, nullptr, 0, 0, nullptr, dc_prev,
+                          dh_prev, dx, dx_channels, dx_channel_stride, dx_accumulate, workspace, mode, nullptr, stream,
+                          h_cur_pixel_stride, dh_state_pixel_stride);
 }
 
 extern "C" int isg_convlstm_bwd_fused_hist_begin(void* hist_scratch, int samples, int hist, void* stream) {

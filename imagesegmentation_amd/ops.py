@@ -633,6 +633,23 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
     B, H, W, F = h_cur.shape
     gates = factors
     assert factors.is_contiguous() and factors.numel() == B * H * W * F * 4 and factors.dtype == torch.bfloat16
+    h_stride = pixel_stride(h_cur)
+    dh_stride = pixel_stride(dh_state) if dh_state is not None else F
+    if h_stride != F or dh_stride != F:
+        # h and / or its carried gradient as 16-channel slices of wider pixels (isg_convlstm_bwd_fused_strided)
+        assert h_stride is not None and dh_stride is not None and packed.hist == 0 and pool == 1
+        if c_prev is not None and c_prev.dtype == torch.bfloat16:
+            mode = int(mode) | CPREV_BF16
+        rc = _lib.lib().isg_convlstm_bwd_fused_strided(
+            _lib.ptr(gates), _lib.ptr(c_prev), h_cur.data_ptr(), int(h_stride),
+            dh_above.data_ptr() if dh_above is not None else None, int(dh_above_batch_stride), int(pool),
+            dh_state.data_ptr() if dh_state is not None else None, int(dh_stride), _lib.ptr(dc_state), _lib.ptr(x),
+            _lib.ptr(h_prev), _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype),
+            _lib.ptr(durations), int(t), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx), int(dx_channels),
+            int(dx.shape[-1]) if dx is not None else 0, int(bool(dx_accumulate)), _lib.ptr(workspace), int(mode),
+            _lib.current_stream())
+        _lib.check(rc, "isg_convlstm_bwd_fused_strided")
+        return
     assert (c_prev is None or c_prev.dtype in (torch.float32, torch.bfloat16)) and h_cur.dtype == torch.bfloat16
     if c_prev is not None and c_prev.dtype == torch.bfloat16:
         mode = int(mode) | CPREV_BF16

@@ -300,6 +300,19 @@ int isg_convlstm_bwd_fused(const void* factors, const void* c_prev, const void* 
                            const int32_t* hist_points, int hist, long long hist_batch_stride, void* hist_scratch,
                            void* dc_prev, void* dh_prev, void* dx, int dx_channels, int dx_channel_stride,
                            int dx_accumulate, void* workspace, int mode, float* dw_x, void* stream);
+/* isg_convlstm_bwd_fused without history taps (hist = 0) for Cs = 48 - one of the two 16-filter groups a 32-filter
+ * cell (reference polyrl/a3c/model.py:21-23) is run as, which share the joint input [features | the other group's h] -
+ * with h_cur and dh_state read as 16-channel slices of wider pixels, h_cur_pixel_stride / dh_state_pixel_stride
+ * elements apart (multiples of 8 in [16, 64]): the group's h where the forward step wrote it, inside the next step's
+ * joint input, and its carried gradient where the other group's backward step wrote it, inside dx - no copies into
+ * arrays of their own. */
+int isg_convlstm_bwd_fused_strided(const void* factors, const void* c_prev, const void* h_cur, int h_cur_pixel_stride,
+                                   const void* dh_above, long long dh_above_batch_stride, int dh_above_pool,
+                                   const void* dh_state, int dh_state_pixel_stride, const void* dc_state, const void* x,
+                                   const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs,
+                                   int F, int dtype, const int32_t* durations, int t, void* dc_prev, void* dh_prev,
+                                   void* dx, int dx_channels, int dx_channel_stride, int dx_accumulate, void* workspace,
+                                   int mode, void* stream);
 
 /* ---- vertex decoding over the class grid ----------------------------------------------------
  * logits: `dtype` [rows][cols] (cols = P*P or P*P + 1).  One wave per row.
