@@ -101,7 +101,7 @@ SIGNATURES = {
     "isg_convlstm_bwd_fused": (_int, [_vp, _vp, _vp, _vp, _ll, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                       _int, _int, _vp, _int, _vp, _int, _ll, _vp, _vp, _vp, _vp, _int, _int, _int, _vp,
                                       _int, _vp, _vp]),
-    "isg_convlstm_bwd_fused_strided": (_int, [_vp, _vp, _vp, _int, _vp, _ll, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int,
+    "isg_convlstm_bwd_fused_strided": (_int, [_vp, _vp, _vp, _int, _vp, _ll, _int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int,
                                               _int, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _int, _int, _int,
                                               _vp, _int, _vp]),
     "isg_convlstm_wgrad_finish": (_int, [_vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),

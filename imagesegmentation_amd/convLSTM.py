@@ -954,8 +954,15 @@ class _WideSequenceFunction(torch.autograd.Function):
         if fused:
             dc_next = [torch.empty_like(g) for g in dc_state]
             dh_next0 = torch.empty_like(dh_state[0])
-        if d_out is not None:  # group-major: one launch of 16-byte moves per group for the whole sequence
+        d_out_in_place = False
+        if d_out is not None:
             d_out_c = d_out if d_out.dtype == dt else d_out.to(dt)
+            # the fused step of the 48-channel kernel reads a group's 16 channels of the joint gradient where they are
+            d_out_in_place = (fused and cs == 48 and tuple(d_out_c.stride()[2:]) == (W * F, F, 1) and
+                              d_out_c.stride(0) % 8 == 0 and not os.environ.get("ISG_NO_STRIDED_BWD"))
+        if d_out_in_place:
+            d_out_g = None
+        elif d_out is not None:  # group-major: one launch of 16-byte moves per group for the whole sequence
             d_out_g = torch.empty([k, B, T, H, W, Fh], dtype=dt, device=dev)
             for s in range(k):
                 ops.copy_slice(d_out_g[s], d_out_c[..., Fh * s:Fh * s + Fh])
@@ -983,10 +990,15 @@ class _WideSequenceFunction(torch.autograd.Function):
                 if fused:
                     # the recurrent input of every group is group 0's h: group 0's gradient of it becomes the carried
                     # one (a finished sample keeps its carried value), the other groups' are added to it below
-                    ops.bwd_fused(Gs[s][t], Cs[s][t], Hs[s][t + 1], d_out_g[s][:, t], T * H * W * Fh, dh_state[s],
-                                  dc_state[s], xw[t], Hs[0][t], groups[s][1], dc_next[s], dh_next0 if s == 0 else dh_extra,
-                                  slabs[s], mode, None, dx=dxw, dx_channels=cs, dx_accumulate=s > 0,
-                                  durations=durations_dev, t=t)
+                    if d_out_in_place:
+                        above = dict(dh_above=d_out_c[:, t, ..., Fh * s:Fh * s + Fh],
+                                     dh_above_batch_stride=d_out_c.stride(0), dh_above_pixel_stride=F)
+                    else:
+                        above = dict(dh_above=d_out_g[s][:, t], dh_above_batch_stride=T * H * W * Fh)
+                    ops.bwd_fused(Gs[s][t], Cs[s][t], Hs[s][t + 1], dh_state=dh_state[s], dc_state=dc_state[s], x=xw[t],
+                                  h_prev=Hs[0][t], packed=groups[s][1], dc_prev=dc_next[s],
+                                  dh_prev=dh_next0 if s == 0 else dh_extra, workspace=slabs[s], mode=mode, dw_x=None,
+                                  dx=dxw, dx_channels=cs, dx_accumulate=s > 0, durations=durations_dev, t=t, **above)
                     dc_state[s], dc_next[s] = dc_next[s], dc_state[s]
                     if s > 0:
                         # (for a finished sample the kernel passes the group's OWN carried gradient through)

@@ -60,6 +60,7 @@ struct BwdParams {
     const void* h_cur;      // [B,H,W,F]: this step's new h
     int h_cur_pstride;      // C0 == 48 only: bytes from pixel to pixel of h_cur and of dh_state (32, or more: 16-channel
     int dh_state_pstride;   // slices of wider pixels - the other group's slot of the joint input and of its gradient)
+    int dh_above_pstride;   // C0 == 48 only: likewise dh_above (the group's 16 channels of the cell's joint output gradient)
     const void* dh_above;   // gradient of the emitted output, sample stride dh_above_bstride
     long long dh_above_bstride;
     int pool_shift;         // > 0: dh_above lives on the grid pooled by 2^s x 2^s windows (average pool)
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
     // gradient as slices of wider pixels; the others keep the constant)
     const unsigned hc_stride = C0 == 48 ? (unsigned)p.h_cur_pstride : 32u;
     const unsigned ds_stride = C0 == 48 ? (unsigned)p.dh_state_pstride : 32u;
+    const unsigned da_stride = C0 == 48 ? (unsigned)p.dh_above_pstride : (unsigned)(F_ * 2);
 
     struct Tile {
         int b, ty0, tx0;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kBwdThreads) void convlstm_bwd_fused_kernel(BwdPara
         shc[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.h_cur) + (size_t)(pixel * hc_stride + q * 8u));
         const unsigned apix = (unsigned)((cy >> p.pool_shift) * (p.W >> p.pool_shift) + (cx >> p.pool_shift));
         sda[j] = *reinterpret_cast<const uint2*>(static_cast<const char*>(p.dh_above) + (size_t)r.b * p.dh_above_bstride * 2 +
-                                                 (size_t)(apix * (unsigned)(F_ * 2) + q * 8u));
+                                                 (size_t)(apix * da_stride + q * 8u));
         if constexpr (no_carry) {
             sds[j] = sdc[j] = make_uint2(0u, 0u);
         } else {
@@ -1140,13 +1142,14 @@ int bwd_fused_impl(const void* gates, const void* c_prev_v, const void* h_cur, c
                    int dtype, const int32_t* durations, int t, const int32_t* hist_points, int hist,
                    long long hist_batch_stride, void* hist_scratch, void* dc_prev, void* dh_prev, void* dx,
                    int dx_channels, int dx_channel_stride, int dx_accumulate, void* workspace, int mode, float* dw_x,
-                   void* stream, int h_cur_pixel_stride, int dh_state_pixel_stride) {
-    ISG_REQUIRE(h_cur_pixel_stride >= F_ && h_cur_pixel_stride <= 64 && h_cur_pixel_stride % 8 == 0 &&
-                    dh_state_pixel_stride >= F_ && dh_state_pixel_stride <= 64 && dh_state_pixel_stride % 8 == 0 &&
-                    (Cs == 48 || (h_cur_pixel_stride == F_ && dh_state_pixel_stride == F_)),
-                ISG_EINVAL,
-                "isg_convlstm_bwd_fused: pixel strides of h_cur / dh_state (%d, %d): multiples of 8 in [16, 64], and 16 "
-                "unless Cs = 48", h_cur_pixel_stride, dh_state_pixel_stride);
+                   void* stream, int h_cur_pixel_stride, int dh_state_pixel_stride, int dh_above_pixel_stride) {
+    {
+        const int strides[3] = {h_cur_pixel_stride, dh_state_pixel_stride, dh_above_pixel_stride};
+        for (int st : strides)
+            ISG_REQUIRE(st >= F_ && st <= 64 && st % 8 == 0 && (Cs == 48 || st == F_), ISG_EINVAL,
+                        "isg_convlstm_bwd_fused: pixel stride %d of h_cur / dh_state / dh_above: a multiple of 8 in "
+                        "[16, 64], and 16 unless Cs = 48", st);
+    }
     // (ISG_HIST_DEFER: the caller zeroes the history scratch once and folds it once, see isg_convlstm_bwd_fused_hist_finish)
     const bool hist_defer = (mode & ISG_HIST_DEFER) != 0;
     const bool cprev_bf16 = (mode & ISG_CPREV_BF16) != 0;
@@ -1185,6 +1188,7 @@ int bwd_fused_impl(const void* gates, const void* c_prev_v, const void* h_cur, c
     BwdParams p = {};
     p.gates = gates, p.c_prev = c_prev, p.cprev_bf16 = cprev_bf16 ? 1 : 0, p.h_cur = h_cur;
     p.h_cur_pstride = h_cur_pixel_stride * 2, p.dh_state_pstride = dh_state_pixel_stride * 2;
+    p.dh_above_pstride = dh_above_pixel_stride * 2;
     p.dh_above = dh_above, p.dh_above_bstride = dh_above_batch_stride, p.pool_shift = pool_shift;
     p.dh_state = dh_state, p.dc_state = dc_state, p.x = x, p.h_prev = h_prev;
     p.B = B, p.H = H, p.W = W, p.durations = durations, p.t = t, p.wimg = packed_dgrad;
@@ -1239,12 +1243,13 @@ extern "C" int isg_convlstm_bwd_fused(const void* gates, const void* c_prev, con
     return bwd_fused_impl(gates, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_above_pool, dh_state, dc_state, x,
                           h_prev, packed_dgrad, B, H, W, C, Cs, F, dtype, durations, t, hist_points, hist,
                           hist_batch_stride, hist_scratch, dc_prev, dh_prev, dx, dx_channels, dx_channel_stride,
-                          dx_accumulate, workspace, mode, dw_x, stream, F_, F_);
+                          dx_accumulate, workspace, mode, dw_x, stream, F_, F_, F_);
 }
 
 extern "C" int isg_convlstm_bwd_fused_strided(const void* gates, const void* c_prev, const void* h_cur,
                                               int h_cur_pixel_stride, const void* dh_above,
-                                              long long dh_above_batch_stride, int dh_above_pool, const void* dh_state,
+                                              long long dh_above_batch_stride, int dh_above_pixel_stride,
+                                              int dh_above_pool, const void* dh_state,
                                               int dh_state_pixel_stride, const void* dc_state, const void* x,
                                               const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C,
                                               int Cs, int F, int dtype, const int32_t* durations, int t, void* dc_prev,
@@ -1253,7 +1258,7 @@ extern "C" int isg_convlstm_bwd_fused_strided(const void* gates, const void* c_p
     return bwd_fused_impl(gates, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_above_pool, dh_state, dc_state, x,
                           h_prev, packed_dgrad, B, H, W, C, Cs, F, dtype, durations, t, nullptr, 0, 0, nullptr, dc_prev,
                           dh_prev, dx, dx_channels, dx_channel_stride, dx_accumulate, workspace, mode, nullptr, stream,
-                          h_cur_pixel_stride, dh_state_pixel_stride);
+                          h_cur_pixel_stride, dh_state_pixel_stride, dh_above_pixel_stride);
 }
 
 extern "C" int isg_convlstm_bwd_fused_hist_begin(void* hist_scratch, int samples, int hist, void* stream) {

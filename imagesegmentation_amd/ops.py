@@ -621,7 +621,7 @@ def bwd_fused_hist_finish(scratch, B, steps, packed, dw_x, accumulate=False):
 @_timed("bwd_fused")
 def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state, dc_state, x, h_prev, packed, dc_prev,
               dh_prev, workspace, mode, dw_x, dx=None, dx_channels=0, dx_accumulate=False, durations=None, t=0,
-              hist_points=None, pool=1, hist_slot=None):
+              hist_points=None, pool=1, hist_slot=None, dh_above_pixel_stride=None):
     """One backward step of the cell in one launch (isg_convlstm_bwd_fused): gate backward from the ``factors``
     the forward step saved (``cell_fwd(save_layout=SAVE_FACTORS)``), the cell state before the step (``c_prev``)
     and the step's new h (``h_cur``); data gradient (dx optional, dh_prev) and
@@ -635,14 +635,16 @@ def bwd_fused(factors, c_prev, h_cur, dh_above, dh_above_batch_stride, dh_state,
     assert factors.is_contiguous() and factors.numel() == B * H * W * F * 4 and factors.dtype == torch.bfloat16
     h_stride = pixel_stride(h_cur)
     dh_stride = pixel_stride(dh_state) if dh_state is not None else F
-    if h_stride != F or dh_stride != F:
-        # h and / or its carried gradient as 16-channel slices of wider pixels (isg_convlstm_bwd_fused_strided)
+    da_stride = F if dh_above_pixel_stride is None else int(dh_above_pixel_stride)
+    if h_stride != F or dh_stride != F or da_stride != F:
+        # h, its carried gradient and / or the output's gradient as 16-channel slices of wider pixels
+        # (isg_convlstm_bwd_fused_strided)
         assert h_stride is not None and dh_stride is not None and packed.hist == 0 and pool == 1
         if c_prev is not None and c_prev.dtype == torch.bfloat16:
             mode = int(mode) | CPREV_BF16
         rc = _lib.lib().isg_convlstm_bwd_fused_strided(
             _lib.ptr(gates), _lib.ptr(c_prev), h_cur.data_ptr(), int(h_stride),
-            dh_above.data_ptr() if dh_above is not None else None, int(dh_above_batch_stride), int(pool),
+            dh_above.data_ptr() if dh_above is not None else None, int(dh_above_batch_stride), da_stride, int(pool),
             dh_state.data_ptr() if dh_state is not None else None, int(dh_stride), _lib.ptr(dc_state), _lib.ptr(x),
             _lib.ptr(h_prev), _lib.ptr(packed.dgrad), B, H, W, packed.c, packed.cs, F, dtype_code(gates.dtype),
             _lib.ptr(durations), int(t), _lib.ptr(dc_prev), _lib.ptr(dh_prev), _lib.ptr(dx), int(dx_channels),

@@ -305,10 +305,11 @@ int isg_convlstm_bwd_fused(const void* factors, const void* c_prev, const void* 
  * with h_cur and dh_state read as 16-channel slices of wider pixels, h_cur_pixel_stride / dh_state_pixel_stride
  * elements apart (multiples of 8 in [16, 64]): the group's h where the forward step wrote it, inside the next step's
  * joint input, and its carried gradient where the other group's backward step wrote it, inside dx - no copies into
- * arrays of their own. */
+ * arrays of their own.  Likewise dh_above, dh_above_pixel_stride elements apart: the group's 16 channels of the
+ * gradient of the cell's joint output (pooling needs dh_above_pixel_stride = 16). */
 int isg_convlstm_bwd_fused_strided(const void* factors, const void* c_prev, const void* h_cur, int h_cur_pixel_stride,
-                                   const void* dh_above, long long dh_above_batch_stride, int dh_above_pool,
-                                   const void* dh_state, int dh_state_pixel_stride, const void* dc_state, const void* x,
+                                   const void* dh_above, long long dh_above_batch_stride, int dh_above_pixel_stride,
+                                   int dh_above_pool, const void* dh_state, int dh_state_pixel_stride, const void* dc_state, const void* x,
                                    const void* h_prev, const void* packed_dgrad, int B, int H, int W, int C, int Cs,
                                    int F, int dtype, const int32_t* durations, int t, void* dc_prev, void* dh_prev,
                                    void* dx, int dx_channels, int dx_channel_stride, int dx_accumulate, void* workspace,
