@@ -39,7 +39,7 @@ SIGNATURES = {
     "isg_bias_relu": (_int, [_vp, _vp, _ll, _int, _int, _vp]),
     "isg_relu_bwd_bias_workspace_bytes": (_ll, [_int]),
     "isg_relu_bwd_bias": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp, _vp]),
-    "isg_relu_bwd_bias_strided": (_int, [_vp, _vp, _ll, _ll, _int, _int, _vp, _vp, _vp, _vp]),
+    "isg_relu_bwd_bias_strided": (_int, [_vp, _ll, _vp, _ll, _ll, _int, _int, _vp, _vp, _vp, _vp]),
     "isg_relu_bwd_bias_static": (_int, [_vp, _vp, _ll, _int, _int, _vp, _vp, _vp]),
     "isg_relu_bwd_bias_static_init": (_int, []),
     "isg_conv_in_packed_elems": (_ll, [_int, _int]),

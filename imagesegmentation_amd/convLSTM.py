@@ -883,6 +883,8 @@ class _WideSequenceFunction(torch.autograd.Function):
             ctx.saved = (xw, Hs, Cs, Gs, groups, layout)
             ctx.in_dtypes = (x_seq.dtype, c0.dtype, h0.dtype)
             ctx.batch_major = T > 1 and B > 1 and x_seq.transpose(0, 1).is_contiguous()
+            ctx.x_in_slots = (x_seq.data_ptr() == xw.data_ptr() and x_seq.dtype == xw.dtype and
+                              x_seq.stride() == xw[..., :C].stride())
             ctx.set_materialize_grads(False)
             # (the final state of an adopted pass is not joined: it sits in the recorder, per group, for who wants it)
             return out, None, None
@@ -1045,7 +1047,11 @@ class _WideSequenceFunction(torch.autograd.Function):
             dbias[cols] = gw[s][2]
         xd, cd, hd = ctx.in_dtypes
         ctx.saved = ctx.cell = None
-        if getattr(ctx, "batch_major", False):
+        if getattr(ctx, "x_in_slots", False) and not os.environ.get("ISG_NO_STRIDED_BWD"):
+            # the input was produced in place, as the first channels of the joint input's wider pixels: its gradient
+            # goes back the same way, as that slice of the joint gradient (the producer's backward reads it there)
+            d_x = d_xw[..., :C]
+        elif getattr(ctx, "batch_major", False):
             d_x = ops.copy_slice(torch.empty([B, T, H, W, C], dtype=dt, device=dev).transpose(0, 1), d_xw[..., :C])
         else:
             d_x = ops.copy_slice(torch.empty([T, B, H, W, C], dtype=dt, device=dev), d_xw[..., :C])

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kBlock) void bias_relu_kernel(T* __restrict__ y, co
 template <typename T>
 __global__ __launch_bounds__(kBlock) void relu_bwd_bias_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                              T* __restrict__ dz, long long nvec, int C,
-                                                             float* __restrict__ partial, int y_vec_stride) {
+                                                             float* __restrict__ partial, int y_vec_stride,
+                                                             int dy_vec_stride) {
     constexpr int N = Vec<T>::N;
     using V = typename Vec<T>::type;
     extern __shared__ float red[];  // [kBlock][N]
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void relu_bwd_bias_kernel(const T* __restri
     for (int k = 0; k < N; ++k) sum[k] = 0.0f;
     const long long start = (long long)blockIdx.x * kBlock + threadIdx.x;
     for (long long i = start; i < nvec; i += (long long)gridDim.x * kBlock) {
-        const V g = reinterpret_cast<const V*>(dy)[i];
+        const V g = reinterpret_cast<const V*>(dy)[dy_vec_stride == C / N ? i : (i / (C / N)) * dy_vec_stride + i % (C / N)];
         // (y may be a channel slice of wider pixels: y_vec_stride vectors from one pixel to the next)
         const V a = reinterpret_cast<const V*>(y)[y_vec_stride == C / N ? i : (i / (C / N)) * y_vec_stride + i % (C / N)];
         V o;
@@ -181,7 +182,7 @@ extern "C" long long isg_relu_bwd_bias_workspace_bytes(int C) {
 
 namespace {
 int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
-                         void* workspace, void* stream, long long y_pixel_stride = 0);
+                         void* workspace, void* stream, long long y_pixel_stride = 0, long long dy_pixel_stride = 0);
 }
 
 extern "C" int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
@@ -192,15 +193,20 @@ extern "C" int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int
     return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, workspace, stream);
 }
 
-extern "C" int isg_relu_bwd_bias_strided(const void* dy, const void* y, long long y_pixel_stride, long long n, int C,
-                                         int dtype, void* dz, float* dbias, void* workspace, void* stream) {
+extern "C" int isg_relu_bwd_bias_strided(const void* dy, long long dy_pixel_stride, const void* y,
+                                         long long y_pixel_stride, long long n, int C, int dtype, void* dz,
+                                         float* dbias, void* workspace, void* stream) {
     int rc = check("isg_relu_bwd_bias_strided", n, C, dtype);
     if (rc != ISG_OK) return rc;
     ISG_REQUIRE(dbias && workspace, ISG_EINVAL, "isg_relu_bwd_bias_strided: null pointer");
     const int N = dtype == ISG_F32 ? 4 : 8;
-    ISG_REQUIRE(y_pixel_stride >= C && y_pixel_stride % N == 0 && y_pixel_stride / N < (1ll << 31), ISG_EINVAL,
-                "isg_relu_bwd_bias_strided: y_pixel_stride %lld (a multiple of %d, at least C = %d)", y_pixel_stride, N, C);
-    return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, workspace, stream, y_pixel_stride);
+    ISG_REQUIRE(y_pixel_stride >= C && y_pixel_stride % N == 0 && y_pixel_stride / N < (1ll << 31) &&
+                    dy_pixel_stride >= C && dy_pixel_stride % N == 0 && dy_pixel_stride / N < (1ll << 31),
+                ISG_EINVAL, "isg_relu_bwd_bias_strided: pixel strides %lld, %lld (multiples of %d, at least C = %d)",
+                dy_pixel_stride, y_pixel_stride, N, C);
+    ISG_REQUIRE(dy_pixel_stride == C || dz != dy, ISG_EINVAL,
+                "isg_relu_bwd_bias_strided: dz (contiguous) cannot alias a dy of wider pixels");
+    return relu_bwd_bias_launch(dy, y, n, C, dtype, dz, dbias, workspace, stream, y_pixel_stride, dy_pixel_stride);
 }
 
 // The partial sums go to this GPU's `scratch` array: no allocation, no workspace argument.  Every row the
@@ -236,9 +242,10 @@ extern "C" int isg_relu_bwd_bias_static_init(void) {
 
 namespace {
 int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
-                         void* workspace, void* stream, long long y_pixel_stride) {
+                         void* workspace, void* stream, long long y_pixel_stride, long long dy_pixel_stride) {
     int rc;
     const int ystride = (int)((y_pixel_stride ? y_pixel_stride : C) / (dtype == ISG_F32 ? 4 : 8));
+    const int dystride = (int)((dy_pixel_stride ? dy_pixel_stride : C) / (dtype == ISG_F32 ? 4 : 8));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) return hipMemsetAsync(dbias, 0, sizeof(float) * C, s) == hipSuccess ? ISG_OK : ISG_ELAUNCH;
     ISG_REQUIRE(dy && y && dz, ISG_EINVAL, "isg_relu_bwd_bias: null pointer");
@@ -249,13 +256,13 @@ int relu_bwd_bias_launch(const void* dy, const void* y, long long n, int C, int 
         grid = grid_for(nvec);
         hipLaunchKernelGGL(relu_bwd_bias_kernel<float>, dim3(grid), dim3(kBlock), kBlock * 4 * sizeof(float), s,
                            static_cast<const float*>(dy), static_cast<const float*>(y), static_cast<float*>(dz), nvec, C,
-                           partial, ystride);
+                           partial, ystride, dystride);
     } else {
         const long long nvec = n * C / 8;
         grid = grid_for(nvec);
         hipLaunchKernelGGL(relu_bwd_bias_kernel<__bf16>, dim3(grid), dim3(kBlock), kBlock * 8 * sizeof(float), s,
                            static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y), static_cast<__bf16*>(dz), nvec,
-                           C, partial, ystride);
+                           C, partial, ystride, dystride);
     }
     if ((rc = isg::check_launch("relu_bwd_bias_kernel")) != ISG_OK) return rc;
     hipLaunchKernelGGL(bias_partial_reduce_kernel, dim3(C), dim3(kBlock), 0, s, partial, grid, C, dbias);

@@ -785,18 +785,18 @@ def relu_bwd_bias(dy, y, dbias_out=None):
     dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given).  ``y`` may be a channel slice of
     wider pixels (``pixel_stride``)."""
     C = y.shape[-1]
-    ystride = pixel_stride(y)
-    assert dy.is_contiguous() and ystride is not None and ystride >= C and dy.shape == y.shape
+    ystride, dystride = pixel_stride(y), pixel_stride(dy)
+    assert ystride is not None and ystride >= C and dystride is not None and dystride >= C and dy.shape == y.shape
     key = (C, str(y.device))
     ws = _bias_ws.get(key)
     if ws is None:
         ws = torch.empty([_lib.lib().isg_relu_bwd_bias_workspace_bytes(C) // 4], dtype=torch.float32, device=y.device)
         _bias_ws[key] = ws
-    dz = torch.empty_like(dy)
+    dz = torch.empty(dy.shape, dtype=dy.dtype, device=dy.device)
     dbias = torch.empty([C], dtype=torch.float32, device=y.device) if dbias_out is None else dbias_out
     assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == C
-    if ystride != C:
-        rc = _lib.lib().isg_relu_bwd_bias_strided(_lib.ptr(dy), y.data_ptr(), ystride, y.numel() // C, C,
+    if ystride != C or dystride != C:
+        rc = _lib.lib().isg_relu_bwd_bias_strided(dy.data_ptr(), dystride, y.data_ptr(), ystride, y.numel() // C, C,
                                                   dtype_code(y.dtype), _lib.ptr(dz), _lib.ptr(dbias), _lib.ptr(ws),
                                                   _lib.current_stream())
         _lib.check(rc, "isg_relu_bwd_bias_strided")

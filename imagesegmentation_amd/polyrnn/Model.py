@@ -173,7 +173,10 @@ class _EncoderChain(torch.autograd.Function):
                 ops.grad_delivered(param)
             else:
                 grads[slot] = value.to(to)
-        dz, dbias = ops.relu_bwd_bias(dy.contiguous(), ys[-1], dbias_out=dst(bs[n - 1]))
+        # (a gradient that is a channel slice of wider pixels - the recurrent cell's joint input gradient - is read in
+        # place)
+        dz, dbias = ops.relu_bwd_bias(dy if ops.pixel_stride(dy) is not None else dy.contiguous(), ys[-1],
+                                      dbias_out=dst(bs[n - 1]))
         for k in range(n - 1, 0, -1):
             ks = ws[k].shape[0]
             hand(2 * k, ws[k], ops.conv32_wgrad(ys[k - 1], dz, ks, out=dst(ws[k])), ctx.dtypes[2 * k])

@@ -482,10 +482,11 @@ int isg_bias_relu(void* y, const float* bias, long long n, int C, int dtype, voi
 long long isg_relu_bwd_bias_workspace_bytes(int C);
 int isg_relu_bwd_bias(const void* dy, const void* y, long long n, int C, int dtype, void* dz, float* dbias,
                       void* workspace, void* stream);
-/* isg_relu_bwd_bias with y as a C-channel slice of wider pixels, y_pixel_stride elements apart (a multiple of the
- * vector width, at least C): the backward of a layer whose output was written by isg_conv32_strided. */
-int isg_relu_bwd_bias_strided(const void* dy, const void* y, long long y_pixel_stride, long long n, int C, int dtype,
-                              void* dz, float* dbias, void* workspace, void* stream);
+/* isg_relu_bwd_bias with dy and y as C-channel slices of wider pixels, dy_pixel_stride / y_pixel_stride elements apart
+ * (multiples of the vector width, at least C): the backward of a layer whose output was written by
+ * isg_conv32_strided, on a gradient that lies inside the gradient of that wider array.  dz is contiguous. */
+int isg_relu_bwd_bias_strided(const void* dy, long long dy_pixel_stride, const void* y, long long y_pixel_stride,
+                              long long n, int C, int dtype, void* dz, float* dbias, void* workspace, void* stream);
 /* isg_relu_bwd_bias without the workspace argument and without any allocation: the per-workgroup partial
  * sums live in an array built into the library (256 KiB per GPU, held until the process ends), whose
  * address is looked up on the first call on each device.  No counterpart in the reference; it is for

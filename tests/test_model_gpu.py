@@ -353,6 +353,12 @@ def test_convolution_into_a_channel_slice_of_wider_pixels(KS):
     dz0, db0 = ops.relu_bwd_bias(dy.clone(), want)
     dz1, db1 = ops.relu_bwd_bias(dy.clone(), slots.view(T * B, H, W, C))
     assert torch.equal(dz0, dz1) and torch.equal(db0, db1)
+    # ... and the gradient itself as such a slice (of the joint input's gradient)
+    dwide = torch.full([T * B, H, W, 48], 3.0, dtype=torch.bfloat16, device=dev)
+    dwide[..., :C] = dy
+    dz2, db2 = ops.relu_bwd_bias(dwide[..., :C], slots.view(T * B, H, W, C))
+    assert dz2.is_contiguous() and torch.equal(dz0, dz2) and torch.equal(db0, db2)
+    assert bool((dwide[..., C:] == 3.0).all()) and torch.equal(dwide[..., :C], dy)
 
 
 @pytest.mark.parametrize("C", [32, 16])
