@@ -762,7 +762,6 @@ def pad_channels(x, cout, out=None):
     return y
 
 
-@_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])
 def pixel_stride(t):
     """Elements from one pixel of ``t`` [..., C] to the next when its pixels are evenly spaced in memory in index order
     (a contiguous tensor: C; a channel slice of a contiguous tensor with wider pixels: that width), else None."""
@@ -780,6 +779,7 @@ def pixel_stride(t):
     return t.shape[-1] if step is None else base
 
 
+@_timed_as(lambda dy, y, dbias_out=None: "relu_bwd_bias[C=%d]" % y.shape[-1])
 def relu_bwd_bias(dy, y, dbias_out=None):
     """(dz, dbias): dz = dy masked by y > 0 (written over dy when dy is contiguous and owns its memory),
     dbias float32 [C] = sum of dz over pixels (into ``dbias_out`` when given).  ``y`` may be a channel slice of
