@@ -145,6 +145,29 @@ def test_points_and_dense_histories_agree_and_train_reduces_loss():
     assert last < first
 
 
+def test_training_step_under_the_launch_timeline():
+    """ops.timeline() (the benchmark's per-launch timing inside a real step): a bf16 training step runs under it,
+    leaves the loss it leaves without it, and files every wrapped launch under its label."""
+    from imagesegmentation_amd import data, ops
+    from imagesegmentation_amd.polyrnn import experiments
+    ds = data.PolygonDataset.synthetic(16, 28, 28, 10, 2, seed=1, shape_mask_fn=oracle_raster.create_shape_mask)
+    np.random.seed(0)
+    d, images, pts, t, _ = ds.get_batch_points(8)
+    losses = []
+    for timed in (False, True):
+        model = experiments.make("History2Large", image_size=28, compute_dtype=torch.bfloat16, device="cuda:0", seed=3)
+        model.train_step(images, d, pts, t)
+        if timed:
+            with ops.timeline() as tl:
+                losses.append(model.train_step(images, d, pts, t).item())
+            labels = tl.summary()
+        else:
+            losses.append(model.train_step(images, d, pts, t).item())
+    assert losses[0] == losses[1]
+    assert any(k.startswith("cell_fwd[") for k in labels) and any(k.startswith("bwd_fused[") for k in labels)
+    assert any(k.startswith("relu_bwd_bias[") for k in labels) and all(v > 0 for v in labels.values())
+
+
 @pytest.mark.parametrize("name", ["History2Large", "EndTokenDeep_2", "History0"])
 def test_validate_iou_follows_the_reference_decode_loop(name):
     """The decode loop (one step per vertex, state fed back, np.roll history) against a NumPy
