@@ -217,11 +217,13 @@ def dense_few_rows(flat, w, b, slices=None):
     N = w.shape[1]
     if slices is None:  # (measured at K = 12,544, N = 785: 16 rows 26 -> 19 us, 2,048 rows 125 -> 82 us)
         slices = 8 if M <= 256 else 4
-    if not (flat.is_cuda and flat.dtype == torch.bfloat16 and w.dtype == flat.dtype and flat.is_contiguous() and
+    # (the rows may lie apart - one step's outputs inside a sequence's kept outputs -, each contiguous in itself)
+    if not (flat.is_cuda and flat.dtype == torch.bfloat16 and w.dtype == flat.dtype and flat.stride(1) == 1 and
+            (M == 1 or (flat.stride(0) >= K and flat.stride(0) % 8 == 0)) and flat.data_ptr() % 16 == 0 and
             w.is_contiguous() and M * N <= (1 << 21) and K % (slices * 8) == 0 and K // slices >= 512):
         return None
     try:
-        part = torch.bmm(flat.view(M, slices, K // slices).transpose(0, 1), w.view(slices, K // slices, N),
+        part = torch.bmm(flat.unflatten(1, (slices, K // slices)).transpose(0, 1), w.view(slices, K // slices, N),
                          out_dtype=torch.float32)
     except TypeError:  # (a torch without float32 results from a bf16 batched GEMM)
         return None

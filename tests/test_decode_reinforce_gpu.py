@@ -417,6 +417,12 @@ def test_head_at_a_handful_of_rows_equals_the_library_gemm():
     assert err <= max(err_one, 2.0 ** -8 * float(ref.abs().max()))
     assert decode.dense_few_rows(flat.float(), w.float(), b.float()) is None
     assert decode.dense_few_rows(flat[:, :1000].contiguous(), w[:1000].contiguous(), b) is None
+    # rows that lie apart (one step of a sequence's kept outputs): the same bits as from a contiguous copy
+    seq = torch.zeros([M, 3, K], dtype=torch.bfloat16, device=d)
+    seq[:, 1] = flat
+    apart = decode.dense_few_rows(seq[:, 1], w, b)
+    assert apart is not None and torch.equal(apart, got)
+    assert decode.dense_few_rows(seq[:, 1, 4:], w[4:], b) is None  # (rows that do not start on 16 bytes' multiples)
 
 
 @pytest.mark.gpu
