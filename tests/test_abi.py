@@ -90,3 +90,36 @@ def test_new_entry_points_reject_bad_arguments_on_the_host():
     # the allocation-free entry point refuses channel counts past its built-in scratch
     assert lib.isg_relu_bwd_bias_static(one, one, 1024, 128, 1, one, one, None) == -1
     assert b"64" in lib.isg_last_error()
+
+
+def test_strided_and_rollout_entry_points_reject_bad_arguments_on_the_host():
+    """The entry points that read or write channel slices of wider pixels, the one-column dense layer and the
+    rollout record: strides that are no multiple of 8 or narrower than the slice, strides where the kernel has none,
+    a slot outside the record, a column count the vector loads cannot take - ISG_EINVAL / ISG_EDTYPE with a message,
+    before any device call."""
+    lib = _lib.lib()
+    one, two = ctypes.c_void_p(4096), ctypes.c_void_p(8192)
+    assert lib.isg_conv32_strided(one, one, None, 1, 8, 8, 3, 1, two, 36, None) == -1
+    assert b"y_pixel_stride" in lib.isg_last_error()
+    assert lib.isg_conv32_strided(one, one, None, 1, 8, 8, 3, 1, two, 24, None) == -1
+    assert lib.isg_conv32_strided(one, one, None, 1, 8, 8, 4, 1, two, 48, None) == -1
+    assert lib.isg_relu_bwd_bias_strided(one, 32, one, 44, 64, 32, 1, two, one, one, None) == -1
+    assert b"pixel strides" in lib.isg_last_error()
+    assert lib.isg_relu_bwd_bias_strided(one, 16, one, 48, 64, 32, 1, two, one, one, None) == -1
+    assert lib.isg_relu_bwd_bias_strided(one, 48, one, 48, 64, 32, 1, one, one, one, None) == -1  # dz over a wide dy
+    assert b"alias" in lib.isg_last_error()
+
+    def fused(cs, h_stride=16, above_stride=16, state_stride=16):
+        return lib.isg_convlstm_bwd_fused_strided(one, one, one, h_stride, one, 0, above_stride, 1, one, state_stride, one,
+                                                  one, one, one, 2, 8, 8, cs, cs, 16, 1, None, 0, two, two, None, 0, 0, 0,
+                                                  one, 2, None)
+
+    assert fused(32, h_stride=48) == -1 and b"unless Cs = 48" in lib.isg_last_error()
+    assert fused(48, above_stride=20) == -1 and fused(48, state_stride=72) == -1 and fused(48, h_stride=8) == -1
+    assert lib.isg_rows_dot(one, one, None, 4, 12, 1, two, None) == -1 and b"multiple of 8" in lib.isg_last_error()
+    assert lib.isg_rows_dot(one, one, None, 4, 16, 0, two, None) != 0 and b"bf16 only" in lib.isg_last_error()
+    assert lib.isg_rows_dot(one, one, None, 0, 16, 1, two, None) == 0
+    assert lib.isg_rollout_record(one, one, one, one, None, 4, 10, 10, two, None, None) == -1
+    assert b"slot" in lib.isg_last_error()
+    assert lib.isg_rollout_record(one, one, one, one, one, 4, 10, 3, two, None, None) == -1  # values without a record
+    assert lib.isg_rollout_record(one, one, one, one, None, 0, 10, 3, two, None, None) == 0
