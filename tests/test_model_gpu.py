@@ -49,7 +49,8 @@ def rel_err(got, ref):
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
 
 
-BF16_GRAD_L2, BF16_GRAD_COS = 3e-1, 0.95  # measured worst: 0.23 and 0.973 (EndTokenDeep_2, first encoder kernel)
+# measured worst over the four nets: 0.077 - 0.111 and 0.9941 - 0.9971 (the deepest tensors of each net)
+BF16_GRAD_L2, BF16_GRAD_COS = 1.5e-1, 0.985
 
 # (the reference runs every graph at 28 x 28; the History0 plumbing configuration is named at 32 x 32, where a row of
 # the grid is exactly one 32-pixel tile wide instead of a partial one)
