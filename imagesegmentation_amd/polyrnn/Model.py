@@ -274,6 +274,33 @@ def _head_weights(dt, w, b, cache):
     return cache["w"], cache["b"]
 
 
+def _head_weights_padded(dt, w, b, cache):
+    """``_head_weights`` with the class axis padded with zero columns to a multiple of 8: a bf16 matrix whose rows are
+    785 elements long (28 x 28 + 1 classes) starts most rows off a 16-byte boundary, and the library's GEMMs over it
+    run a quarter slower than over 792 columns.  A copy of its own beside the unpadded one (which the few-row paths
+    of the decode and acting loops keep using)."""
+    K, N = w.shape
+    Np = (N + 7) // 8 * 8
+    reg = ops.active_derived()
+    rkey = ("head8", w.data_ptr(), b.data_ptr(), dt)
+    if reg is not None:
+        e = reg.get(rkey)
+        if e is not None:
+            return e.w, e.b
+    key = (dt, w._version, b._version, w.data_ptr(), ops.weights_epoch())
+    if cache.get("key8") != key:
+        wp = torch.zeros([K, Np], dtype=dt, device=w.device)
+        bp = torch.zeros([Np], dtype=dt, device=w.device)
+        wp[:, :N].copy_(w.detach())
+        bp[:N].copy_(b.detach())
+        cache["key8"], cache["w8"], cache["b8"] = key, wp, bp
+        if reg is not None and dt == torch.bfloat16 and reg.owns(w.detach(), b.detach()):
+            import types
+            ns = types.SimpleNamespace(w=wp, b=bp)
+            reg.record(rkey, ns, ["w", "b"], lambda: (ns.w[:, :N].copy_(w.detach()), ns.b[:N].copy_(b.detach())), [w, b])
+    return cache["w8"], cache["b8"]
+
+
 class _DenseHead(torch.autograd.Function):
     """logits = flat @ W + b (reference polyrnn/History2LargeExperiment.py:48-50) with float32 master weights and
     activations in the compute type: the library GEMM runs in the compute type on copies of the weights that are
@@ -283,16 +310,38 @@ class _DenseHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, w, b, cache):
-        wc, bc = _head_weights(flat.dtype, w, b, cache)
+        N = w.shape[1]
+        # (many rows against a class axis that is no multiple of 8: the GEMMs run on the padded copy)
+        ctx.padded = (N % 8 != 0 and N >= 64 and flat.is_cuda and flat.dtype == torch.bfloat16 and
+                      flat.shape[0] >= 2048 and not os.environ.get("ISG_NO_PADDED_HEAD"))
+        wc, bc = (_head_weights_padded if ctx.padded else _head_weights)(flat.dtype, w, b, cache)
         ctx.save_for_backward(flat, wc)
         ctx.params = (w.detach(), b.detach())
-        return torch.addmm(bc, flat, wc)
+        out = torch.addmm(bc, flat, wc)
+        return out[:, :N].contiguous() if ctx.padded else out
 
     @staticmethod
     def backward(ctx, dlogits):
         flat, wc = ctx.saved_tensors
         w, b = ctx.params
         dlogits = dlogits.contiguous()
+        if ctx.padded:
+            N = w.shape[1]
+            d = dlogits.new_zeros([dlogits.shape[0], wc.shape[1]])
+            d[:, :N] = dlogits
+            d_flat = d @ wc.t() if ctx.needs_input_grad[0] else None
+            dw = (flat.t() @ d)[:, :N]
+            db = decode.column_sums(dlogits)
+            out = []
+            for prm, g in ((w, dw), (b, db)):
+                dst = ops.grad_destination(prm)
+                if dst is not None:
+                    dst.copy_(g)
+                    ops.grad_delivered(prm)
+                    out.append(None)
+                else:
+                    out.append(g.to(prm.dtype))
+            return d_flat, out[0], out[1], None
         d_flat = dlogits @ wc.t() if ctx.needs_input_grad[0] else None
         if dlogits.shape[1] < 8 and dlogits.is_cuda:
             # a head of a few columns (the actor-critic value head has one): as [K, R] x [R, 1] the library takes a
