@@ -898,3 +898,38 @@ def test_padded_input_layer_on_the_square_kernels(KS, C, cin):
     gw = wd.grad.permute(2, 3, 1, 0)
     assert (w.grad.double() - gw).abs().max().item() <= 3e-2 * gw.abs().max().item()
     assert (b.grad.double() - bd.grad).abs().max().item() <= 3e-2 * bd.grad.abs().max().item()
+
+
+def test_dense_head_on_the_padded_class_axis(monkeypatch):
+    """_DenseHead over many rows runs its three GEMMs on a copy of the weights padded to a multiple of 8 classes:
+    same logits and gradients as on the unpadded copy (bf16 GEMMs whose reduction splits may differ), pad columns
+    zero, nothing of the padding in what comes back."""
+    from imagesegmentation_amd.polyrnn import Model as M
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    R, K, N = 2048, 1568, 785
+    flat0 = (torch.randn([R, K], device="cuda:0", generator=g) * 0.5).bfloat16()
+    w = torch.nn.Parameter(torch.randn([K, N], device="cuda:0", generator=g) * 0.02)
+    b = torch.nn.Parameter(torch.randn([N], device="cuda:0", generator=g) * 0.1)
+    up = torch.randn([R, N], device="cuda:0", generator=g).bfloat16()
+    res = {}
+    for padded in (True, False):
+        if not padded:
+            monkeypatch.setenv("ISG_NO_PADDED_HEAD", "1")
+        cache = {}
+        flat = flat0.clone().requires_grad_(True)
+        w.grad = b.grad = None
+        out = M._DenseHead.apply(flat, w, b, cache)
+        assert tuple(out.shape) == (R, N) and out.is_contiguous()
+        out.backward(up)
+        res[padded] = (out.detach().float(), flat.grad.float(), w.grad.clone(), b.grad.clone())
+        if padded:
+            assert tuple(cache["w8"].shape) == (K, 792) and not bool(cache["w8"][:, N:].any()) and not bool(cache["b8"][N:].any())
+        else:
+            assert "w8" not in cache
+    ref = flat0.double() @ w.detach().bfloat16().double() + b.detach().bfloat16().double()
+    scale = float(ref.abs().max())
+    for padded in (True, False):
+        assert float((res[padded][0].double() - ref).abs().max()) <= 2.0 ** -7 * scale
+    for a, c in zip(res[True][1:], res[False][1:]):
+        assert a.shape == c.shape
+        assert float((a - c).abs().max()) <= 2.0 ** -6 * float(c.abs().max())
