@@ -79,6 +79,7 @@ SIGNATURES = {
     "isg_decode_begin": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "isg_decode_polygons": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "isg_sum_slices_bias": (_int, [_vp, _int, _int, _int, _vp, _int, _vp, _vp]),
+    "isg_sum_slices_bias_padded": (_int, [_vp, _int, _int, _int, _int, _vp, _int, _vp, _vp]),
     "isg_rows_dot": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
     "isg_pad_channels": (_int, [_vp, _int, _int, _vp, _int, _ll, _vp]),
     "isg_adam_tf": (_int, [_vp, _vp, _vp, _vp, _ll, _f64, _f64, _f64, _f64, _vp, _f64, _vp]),

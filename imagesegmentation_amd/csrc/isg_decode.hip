@@ -451,11 +451,14 @@ __global__ __launch_bounds__(256) void decode_polygons_kernel(const int32_t* __r
 // out[r][c] = sum over slices of part[s][r][c] + bias[c], in the order of the slices
 template <typename T>
 __global__ __launch_bounds__(256) void sum_slices_bias_kernel(const float* __restrict__ part, int slices, long long n,
-                                                              int cols, const T* __restrict__ bias, T* __restrict__ out) {
+                                                              int cols, const T* __restrict__ bias, T* __restrict__ out,
+                                                              int part_cols, long long slice_stride) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // (the partial results may have more columns than are wanted: a weight matrix padded with zero columns)
+    const long long src = part_cols == cols ? i : (i / cols) * part_cols + i % cols;
     float v = 0.0f;
-    for (int s = 0; s < slices; ++s) v += part[(long long)s * n + i];
+    for (int s = 0; s < slices; ++s) v += part[(long long)s * slice_stride + src];
     out[i] = (T)(v + (float)bias[i % cols]);
 }
 
@@ -687,23 +690,37 @@ extern "C" int isg_decode_polygons(const int32_t* predicted, const int32_t* dura
     return isg::check_launch("decode_polygons_kernel");
 }
 
-extern "C" int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype,
-                                   void* out, void* stream) {
-    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "isg_sum_slices_bias: dtype %d", dtype);
-    ISG_REQUIRE(slices >= 1 && rows >= 0 && cols >= 1, ISG_EINVAL, "isg_sum_slices_bias: slices=%d rows=%d cols=%d", slices,
-                rows, cols);
+namespace {
+int sum_slices_bias_impl(const char* who, const float* part, int slices, int rows, int cols, int part_cols,
+                         const void* bias, int dtype, void* out, void* stream) {
+    ISG_REQUIRE(dtype == ISG_F32 || dtype == ISG_BF16, ISG_EDTYPE, "%s: dtype %d", who, dtype);
+    ISG_REQUIRE(slices >= 1 && rows >= 0 && cols >= 1 && part_cols >= cols, ISG_EINVAL,
+                "%s: slices=%d rows=%d cols=%d part_cols=%d", who, slices, rows, cols, part_cols);
     if (rows == 0) return ISG_OK;
-    ISG_REQUIRE(part && bias && out, ISG_EINVAL, "isg_sum_slices_bias: null pointer");
+    ISG_REQUIRE(part && bias && out, ISG_EINVAL, "%s: null pointer", who);
     const long long n = (long long)rows * cols;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long slice_stride = (long long)rows * part_cols;
     if (dtype == ISG_F32)
         hipLaunchKernelGGL(sum_slices_bias_kernel<float>, grid, block, 0, s, part, slices, n, cols,
-                           static_cast<const float*>(bias), static_cast<float*>(out));
+                           static_cast<const float*>(bias), static_cast<float*>(out), part_cols, slice_stride);
     else
         hipLaunchKernelGGL(sum_slices_bias_kernel<__hip_bfloat16>, grid, block, 0, s, part, slices, n, cols,
-                           static_cast<const __hip_bfloat16*>(bias), static_cast<__hip_bfloat16*>(out));
+                           static_cast<const __hip_bfloat16*>(bias), static_cast<__hip_bfloat16*>(out), part_cols,
+                           slice_stride);
     return isg::check_launch("sum_slices_bias_kernel");
+}
+}  // namespace
+
+extern "C" int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype,
+                                   void* out, void* stream) {
+    return sum_slices_bias_impl("isg_sum_slices_bias", part, slices, rows, cols, cols, bias, dtype, out, stream);
+}
+
+extern "C" int isg_sum_slices_bias_padded(const float* part, int slices, int rows, int cols, int part_cols,
+                                          const void* bias, int dtype, void* out, void* stream) {
+    return sum_slices_bias_impl("isg_sum_slices_bias_padded", part, slices, rows, cols, part_cols, bias, dtype, out, stream);
 }
 
 extern "C" int isg_rows_dot(const void* x, const void* w, const void* bias, int rows, int cols, int dtype, float* out,

@@ -645,10 +645,19 @@ class Model:
             logits = _DenseHead.apply(flat, w, b, self._head_cache)
         elif flat.dtype != w.dtype:
             # decode loops call the head once per step with unchanged weights: convert them once
-            wc, bc = _head_weights(flat.dtype, w, b, self._head_cache)
-            logits = decode.dense_few_rows(flat, wc, bc) if not os.environ.get("ISG_NO_SPLIT_HEAD") else None
-            if logits is None:
-                logits = torch.addmm(bc, flat, wc)
+            N = w.shape[1]
+            if (N % 8 != 0 and N >= 64 and flat.is_cuda and flat.dtype == torch.bfloat16 and flat.shape[0] >= 2048 and
+                    not os.environ.get("ISG_NO_PADDED_HEAD")):
+                # (many rows: the copy padded to a multiple of 8 classes, as in ``_DenseHead``)
+                wc, bc = _head_weights_padded(flat.dtype, w, b, self._head_cache)
+                logits = decode.dense_few_rows(flat, wc, bc[:N]) if not os.environ.get("ISG_NO_SPLIT_HEAD") else None
+                if logits is None:
+                    logits = torch.addmm(bc, flat, wc)[:, :N]
+            else:
+                wc, bc = _head_weights(flat.dtype, w, b, self._head_cache)
+                logits = decode.dense_few_rows(flat, wc, bc) if not os.environ.get("ISG_NO_SPLIT_HEAD") else None
+                if logits is None:
+                    logits = torch.addmm(bc, flat, wc)
         else:
             logits = torch.addmm(b.detach(), flat, w.detach()) if not torch.is_grad_enabled() else torch.addmm(b, flat, w)
         return logits.reshape(B, T, self.num_classes)

@@ -214,7 +214,7 @@ def dense_few_rows(flat, w, b, slices=None):
     into ``slices`` batched GEMMs with float results, summed with the bias by one launch (isg_sum_slices_bias).
     None when the shape does not call for it (the caller's plain GEMM then)."""
     M, K = flat.shape
-    N = w.shape[1]
+    N = b.numel()  # (w may carry zero columns beyond the bias's classes: a copy padded to a multiple of 8)
     if slices is None:  # (measured at K = 12,544, N = 785: 16 rows 26 -> 19 us, 2,048 rows 125 -> 82 us)
         slices = 8 if M <= 256 else 4
     # (the rows may lie apart - one step's outputs inside a sequence's kept outputs -, each contiguous in itself)
@@ -223,21 +223,23 @@ def dense_few_rows(flat, w, b, slices=None):
             w.is_contiguous() and M * N <= (1 << 21) and K % (slices * 8) == 0 and K // slices >= 512):
         return None
     try:
-        part = torch.bmm(flat.unflatten(1, (slices, K // slices)).transpose(0, 1), w.view(slices, K // slices, N),
-                         out_dtype=torch.float32)
+        part = torch.bmm(flat.unflatten(1, (slices, K // slices)).transpose(0, 1),
+                         w.view(slices, K // slices, w.shape[1]), out_dtype=torch.float32)
     except TypeError:  # (a torch without float32 results from a bf16 batched GEMM)
         return None
     return sum_slices_bias(part, b)
 
 
 def sum_slices_bias(part, b):
-    """part float32 [slices, M, N] summed over the slices + b [N], in b's type (float32 or bf16), in one launch."""
-    slices, M, N = part.shape
-    assert part.dtype == torch.float32 and part.is_contiguous() and b.numel() == N
+    """part float32 [slices, M, Np] summed over the slices + b [N], N <= Np (the first N columns are kept), in b's type
+    (float32 or bf16), in one launch."""
+    slices, M, Np = part.shape
+    N = b.numel()
+    assert part.dtype == torch.float32 and part.is_contiguous() and N <= Np
     out = torch.empty([M, N], dtype=b.dtype, device=part.device)
-    rc = _lib.lib().isg_sum_slices_bias(_lib.ptr(part), slices, M, N, _lib.ptr(b.contiguous()), dtype_code(out.dtype),
-                                        _lib.ptr(out), _lib.current_stream())
-    _lib.check(rc, "isg_sum_slices_bias")
+    rc = _lib.lib().isg_sum_slices_bias_padded(_lib.ptr(part), slices, M, N, Np, _lib.ptr(b.contiguous()),
+                                               dtype_code(out.dtype), _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "isg_sum_slices_bias_padded")
     return out
 
 

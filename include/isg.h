@@ -399,6 +399,11 @@ int isg_decode_polygons(const int32_t* predicted, const int32_t* durations, cons
  * handful of rows (polyrnn/Model.py:231-249 runs it once per vertex), where one GEMM has too few output tiles. */
 int isg_sum_slices_bias(const float* part, int slices, int rows, int cols, const void* bias, int dtype, void* out,
                         void* stream);
+/* isg_sum_slices_bias over partial results of part_cols >= cols columns each ([slices][rows][part_cols]; the first cols
+ * are kept): the batched GEMMs ran on a weight matrix padded with zero columns to a multiple of 8, so that its bf16
+ * rows start on 16-byte boundaries (785 = 28 x 28 + 1 classes -> 792). */
+int isg_sum_slices_bias_padded(const float* part, int slices, int rows, int cols, int part_cols, const void* bias,
+                               int dtype, void* out, void* stream);
 
 /* out float [rows] = x [rows][cols] . w [cols] + bias[0] (bias may be NULL), x, w and bias bf16: a dense layer with one
  * output column - the value head of polyrl/a3c/model.py:39 at an acting step, which as a library GEMM is a

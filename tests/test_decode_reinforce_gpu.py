@@ -417,6 +417,13 @@ def test_head_at_a_handful_of_rows_equals_the_library_gemm():
     assert err <= max(err_one, 2.0 ** -8 * float(ref.abs().max()))
     assert decode.dense_few_rows(flat.float(), w.float(), b.float()) is None
     assert decode.dense_few_rows(flat[:, :1000].contiguous(), w[:1000].contiguous(), b) is None
+    # a weight matrix padded with zero columns to a multiple of 8 (rows on 16-byte boundaries): the first N columns,
+    # no further from float64 than the unpadded result
+    wp = torch.zeros([K, 792], dtype=torch.bfloat16, device=d)
+    wp[:, :N] = w
+    padded = decode.dense_few_rows(flat, wp, b)
+    assert padded is not None and tuple(padded.shape) == (M, N)
+    assert float((padded.double() - ref).abs().max()) <= max(err_one, 2.0 ** -8 * float(ref.abs().max()))
     # rows that lie apart (one step of a sequence's kept outputs): the same bits as from a contiguous copy
     seq = torch.zeros([M, 3, K], dtype=torch.bfloat16, device=d)
     seq[:, 1] = flat
