@@ -983,3 +983,58 @@ def test_bf16_cell_state_is_the_float_state_rounded_once(cs, hist, shape):
     x32 = torch.randn([B, H, W, 16], device=d)
     c4 = ConvLSTMCell([H, W], 16, [3, 3], compute_dtype=torch.float32, device=d).build(16, d)
     assert not ops.state_bf16_supported(c4.packed(), B, H, W)
+
+
+@pytest.mark.parametrize("C,F", [(32, 32), (16, 48)])
+def test_recorded_wide_pass_gives_the_gradients_of_a_pass_of_its_own(C, F):
+    """A 32-filter (two groups) and a 48-filter (three groups) cell over whole sequences, bf16, no lengths - the
+    sweep in which every further group's h, its carried gradient and the groups' channels of the output gradient are
+    read in place as slices of wider pixels.  (1) dynamic_rnn against the float64 oracle.  (2) The same sequence
+    advanced step by step by WideRecorder and adopted (its h slices live inside the next step's joint input, its
+    outputs are time-major): outputs and every gradient bit for bit those of the pass dynamic_rnn runs itself - the
+    same kernels on the same numbers through other strides."""
+    from imagesegmentation_amd.convLSTM import ConvLSTMCell, LSTMStateTuple, SequenceInput, WideRecorder, dynamic_rnn
+    rs = np.random.RandomState(100 + F)
+    dt, d = torch.bfloat16, dev()
+    T, B, H, W = 3, 2, 12, 40
+    w_x, w_h, bias = rand_cell(rs, C, F=F)
+    cell = ConvLSTMCell(shape=[H, W], filters=F, kernel=[3, 3], compute_dtype=dt, device=d)
+    cell.build(C, d)
+    with torch.no_grad():
+        cell.input_to_state_kernel.copy_(torch.tensor(w_x))
+        cell.hidden_to_state_kernel.copy_(torch.tensor(w_h))
+        cell.bias.copy_(torch.tensor(bias))
+    x = torch.tensor(rs.randn(T, B, H, W, C), device=d).to(dt)
+    d_out = torch.tensor(rs.randn(B, T, H, W, F), device=d).to(dt)
+    params = [cell.input_to_state_kernel, cell.hidden_to_state_kernel, cell.bias]
+    runs = []
+    for recorded in (False, True):
+        for p in params:
+            p.grad = None
+        xs = x.clone().requires_grad_(True)
+        seq = SequenceInput(x_seq=xs)
+        if recorded:
+            rec = WideRecorder(cell, B, d, T)
+            with torch.no_grad():
+                steps = [rec.step(x[t]).clone() for t in range(T)]
+            seq.recorded = rec.record()
+        out, _ = dynamic_rnn(cell, seq, initial_state=LSTMStateTuple(*cell.zero_state(B, d)), time_major=False)
+        assert tuple(out.shape) == (B, T, H, W, F)
+        if recorded:
+            assert out.transpose(0, 1).is_contiguous() and all(torch.equal(steps[t], out[:, t]) for t in range(T))
+        (out.float() * d_out.float()).sum().backward()
+        runs.append((out.detach().clone(), xs.grad.clone()) + tuple(p.grad.clone() for p in params))
+    for own, adopted in zip(*runs):
+        assert torch.equal(own, adopted)
+    r = lambda a: torch.tensor(a).to(torch.bfloat16).double().numpy()
+    oparams = _round_params([dict(w_x=w_x, w_h=w_h, bias=bias)])
+    durations = np.full([B], T, np.int32)
+    init = [(np.zeros([B, H, W, F]), np.zeros([B, H, W, F]))]
+    ro, rf, caches = oc.rnn_forward(x.double().cpu().numpy(), durations, oparams, init, return_cache=True)
+    close(runs[0][0].transpose(0, 1), ro, dt, "outputs")
+    d_fin = [(np.zeros([B, H, W, F]), np.zeros([B, H, W, F]))]
+    d_in, grads, _ = oc.rnn_backward(caches, durations, oparams, d_out.double().cpu().numpy().transpose(1, 0, 2, 3, 4), d_fin)
+    close(runs[0][1], d_in, dt, "d_inputs")
+    close(runs[0][2], grads[0]["dw_x"], dt, "dw_x")
+    close(runs[0][3], grads[0]["dw_h"], dt, "dw_h")
+    close(runs[0][4], grads[0]["dbias"], dt, "dbias")
