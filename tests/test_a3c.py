@@ -354,3 +354,46 @@ def test_fused_loss_against_the_tensor_form(dtype, monkeypatch):
     assert float((logits.grad.double() - z64.grad).abs().max()) <= tol * float(z64.grad.abs().max())
     assert float((vf.grad.double() - v64.grad).abs().max()) <= 1e-6
     assert float(logits.grad[~live].abs().max()) == 0.0 and float(vf.grad[~live].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_joint_backward_of_the_two_heads_against_the_separate_ones(monkeypatch):
+    """LSTMPolicy._heads with grad enabled: the action and value heads as one node whose backward runs one layer of
+    A + 1 columns (_JointHeads) against the two separate dense-head nodes (ISG_NO_JOINT_HEADS): the same logits and
+    values bit for bit (the forward GEMMs are the same), the same gradients up to the bf16 rounding of GEMMs whose
+    reductions split differently, and both against float64."""
+    from imagesegmentation_amd.polyrl import a3c
+    dev = torch.device("cuda:0")
+    P = 16
+    pol = a3c.LSTMPolicy((P, P, 5), P * P, compute_dtype=torch.bfloat16, device=dev, seed=3)
+    g = torch.Generator(device=dev).manual_seed(4)
+    R, K = 96, P * P * 32
+    flat0 = (torch.randn([R, K], device=dev, generator=g) * 0.5).bfloat16()
+    up_l = torch.randn([R, P * P], device=dev, generator=g)
+    up_v = torch.randn([R], device=dev, generator=g)
+    heads = [pol.action_kernel, pol.action_bias, pol.value_kernel, pol.value_bias]
+    res = {}
+    for joint in (True, False):
+        if not joint:
+            monkeypatch.setenv("ISG_NO_JOINT_HEADS", "1")
+        for p in heads:
+            p.grad = None
+        flat = flat0.clone().requires_grad_(True)
+        logits, vf = pol._heads(flat)
+        assert logits.dtype == torch.float32 and tuple(logits.shape) == (R, P * P) and tuple(vf.shape) == (R,)
+        ((logits * up_l).sum() + (vf * up_v).sum()).backward()
+        res[joint] = [logits.detach().clone(), vf.detach().clone(), flat.grad.float()] + [p.grad.clone() for p in heads]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2:], res[False][2:]):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
+    # float64 on the operands the GEMMs see (bf16 weights and upstream gradients)
+    bf = lambda t: t.detach().bfloat16().double()
+    d = torch.cat([bf(up_l), bf(up_v)[:, None]], dim=1)
+    wj = torch.cat([bf(pol.action_kernel), bf(pol.value_kernel)], dim=1)
+    ref_flat = d @ wj.t()
+    ref_w = flat0.double().t() @ d
+    assert float((res[True][2].double() - ref_flat).abs().max()) <= 2.0 ** -7 * float(ref_flat.abs().max())
+    assert float((res[True][3].double() - ref_w[:, :-1]).abs().max()) <= 2.0 ** -7 * float(ref_w.abs().max())
+    assert float((res[True][5].double() - ref_w[:, -1:]).abs().max()) <= 2.0 ** -7 * float(ref_w.abs().max())
+    assert float((res[True][4].double() - d[:, :-1].sum(0)).abs().max()) <= 1e-4 * float(d.abs().sum(0).max())
+    assert float((res[True][6].double() - d[:, -1:].sum(0)).abs().max()) <= 1e-4 * float(d.abs().sum(0).max())
